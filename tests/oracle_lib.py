@@ -1,0 +1,113 @@
+"""ctypes binding of the CPU oracle (oracle/libgpis_oracle.so) -- test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+fp = C.POINTER(C.c_float)
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(ORACLE_DIR, "libgpis_oracle.so")
+        if not os.path.exists(path):
+            build()
+        L = C.CDLL(path)
+        L.orc3_create.restype = C.c_void_p
+        L.orc3_create.argtypes = [dp]
+        for name in ("orc3_destroy", "orc3_reset"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc3_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc3_set_camera.argtypes = [C.c_void_p, dp]
+        L.orc3_update.argtypes = [C.c_void_p, fp, C.c_int, fp]
+        L.orc3_test.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, fp]
+        L.orc3_num_points.argtypes = [C.c_void_p]
+        L.orc3_get_points.argtypes = [C.c_void_p, fp, C.c_int]
+        L.orc3_get_nodes.argtypes = [C.c_void_p, fp, C.c_int]
+        L.orc3_num_clusters.argtypes = [C.c_void_p]
+        L.orc3_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        L.orc3_obsgp_query.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
+        L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.orc_bwd_subst.argtypes = [fp, C.c_int, C.c_int, fp]
+        L.orc_gpou_train.argtypes = [fp, fp, C.c_int, C.c_int, fp, fp]
+        L.orc_gpou_test.argtypes = [fp, fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]
+        L.orc_ongpis_train.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp, fp, C.c_int, fp, fp, ip]
+        L.orc_matern32_train.argtypes = [C.c_int, C.c_int, fp, ip, C.c_int, C.c_float, fp, fp, fp]
+        L.orc_matern32_cross.argtypes = [C.c_int, C.c_int, fp, ip, C.c_int, C.c_float, fp, fp]
+        L.orc_ongpis_predict.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, fp]
+        _LIB = L
+    return _LIB
+
+
+class OracleMap3:
+    """Mirror of the reference's mexGPisMap3 command set on the CPU oracle."""
+
+    def __init__(self, cam6=None, threads=None):
+        self.L = lib()
+        c = None if cam6 is None else _p(np.ascontiguousarray(cam6, dtype=np.float64), C.c_double)
+        self.h = C.c_void_p(self.L.orc3_create(c))
+        if threads:
+            self.L.orc3_set_threads(self.h, threads)
+
+    def close(self):
+        if self.h:
+            self.L.orc3_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_camera(self, cam6):
+        self.L.orc3_set_camera(self.h, _p(np.ascontiguousarray(cam6, dtype=np.float64), C.c_double))
+
+    def update(self, depth, pose):
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        pose = np.ascontiguousarray(pose, dtype=np.float32)
+        self.L.orc3_update(self.h, _p(depth), depth.size, _p(pose))
+
+    def test(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        res = np.zeros((x.shape[0], 8), dtype=np.float32)
+        ok = self.L.orc3_test(self.h, _p(x), 3, x.shape[0], _p(res))
+        return res if ok else None
+
+    def num_points(self):
+        return self.L.orc3_num_points(self.h)
+
+    def nodes(self):
+        n = self.L.orc3_get_nodes(self.h, None, 0)
+        out = np.zeros((n, 9), dtype=np.float32)
+        if n:
+            self.L.orc3_get_nodes(self.h, _p(out), n)
+        return out
+
+    def num_clusters(self):
+        return self.L.orc3_num_clusters(self.h)
+
+    def stats(self):
+        a = (C.c_long * 6)()
+        self.L.orc3_stats(self.h, a)
+        return dict(zip(("obsgp_tiles", "obsgp_queries", "clusters_trained", "sumK", "maxK", "gp_evals"), list(a)))
+
+    def obsgp_query(self, vu):
+        vu = np.ascontiguousarray(vu, dtype=np.float32)
+        n = vu.shape[0]
+        val = np.zeros(n, dtype=np.float32)
+        var = np.zeros(n, dtype=np.float32)
+        self.L.orc3_obsgp_query(self.h, _p(vu), n, _p(val), _p(var))
+        return val, var
