@@ -1,0 +1,263 @@
+"""gpismap_amd -- MI355X-native GPisMap hot path (ObsGP + OnGPIS on hand-written HIP kernels).
+
+Thin ctypes binding of the C-ABI in include/gpismap_amd.h.  The classes mirror the command set of
+the reference's mex gateways (mex/mexGPisMap3.cpp: 'setCamera' / 'update' / 'test' /
+'getAllPoints' / 'reset').  There is NO CPU fallback: if libgpismap_amd.so is missing, or no HIP
+device is present, the compute entry points raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpismap_amd.so")
+_lib = None
+
+fp = C.POINTER(C.c_float)
+ip = C.POINTER(C.c_int)
+dp = C.POINTER(C.c_double)
+
+
+class GpisError(RuntimeError):
+    pass
+
+
+class gpis_cam(C.Structure):
+    _fields_ = [("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+                ("width", C.c_int), ("height", C.c_int)]
+
+
+def _p(a, t=C.c_float):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def lib():
+    """Load the native library (built in-tree by __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpisError("native library %s not built; run __graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.gpis_device_count.restype = C.c_int
+    L.gpis_version.restype = C.c_char_p
+    L.gpis3_create.restype = vp
+    L.gpis3_create.argtypes = [C.POINTER(gpis_cam)]
+    L.gpis3_destroy.argtypes = [vp]
+    L.gpis3_reset.argtypes = [vp]
+    L.gpis3_set_camera.argtypes = [vp, C.POINTER(gpis_cam)]
+    L.gpis3_update.argtypes = [vp, fp, C.c_int, fp]
+    L.gpis3_test.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.gpis3_test_device.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.gpis3_num_points.argtypes = [vp]
+    L.gpis3_get_points.argtypes = [vp, fp, C.c_int]
+    L.gpis3_get_nodes.argtypes = [vp, fp, C.c_int]
+    L.gpis3_stats.argtypes = [vp, dp, C.c_int]
+    L.gpis3_set_profile.argtypes = [vp, C.c_int]
+    L.gpis_obsgp_create.restype = vp
+    L.gpis_obsgp_destroy.argtypes = [vp]
+    L.gpis_obsgp_train2d.argtypes = [vp, fp, fp, C.c_int, C.c_int]
+    L.gpis_obsgp_train1d.argtypes = [vp, fp, fp, C.c_int]
+    L.gpis_obsgp_query.argtypes = [vp, fp, C.c_int, fp, fp]
+    L.gpis_obsgp_num_groups.argtypes = [vp]
+    L.gpis_obsgp_get_group.argtypes = [vp, C.c_int, ip, fp, fp, fp]
+    L.gpis_ongpis_create.restype = vp
+    L.gpis_ongpis_create.argtypes = [C.c_int, C.c_float]
+    L.gpis_ongpis_destroy.argtypes = [vp]
+    L.gpis_ongpis_train.argtypes = [vp, fp, C.c_int, ip, ip, C.c_int, ip]
+    L.gpis_ongpis_model_dims.argtypes = [vp, C.c_int, ip]
+    L.gpis_ongpis_get_model.argtypes = [vp, C.c_int, fp, fp, ip]
+    L.gpis_ongpis_eval.argtypes = [vp, fp, C.c_int, ip, ip, C.c_int, fp]
+    L.gpis_ongpis_last_ms.argtypes = [vp, fp, fp]
+    _lib = L
+    return L
+
+
+def device_count():
+    return lib().gpis_device_count()
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise GpisError("%s failed with status %d" % (what, rc))
+
+
+def _cam(cam6):
+    c = np.asarray(cam6, dtype=np.float64)
+    return gpis_cam(float(c[0]), float(c[1]), float(c[2]), float(c[3]), int(c[4]), int(c[5]))
+
+
+class GPisMap3:
+    """Mirror of the reference's mexGPisMap3 command set on the HIP path."""
+
+    STAT_KEYS = ("obsgp_groups", "obsgp_queries", "clusters_trained", "late_reevals", "clusters",
+                 "last_test_evals", "last_test_k4_ms", "device_bytes")
+
+    def __init__(self, cam6=None):
+        self.L = lib()
+        if self.L.gpis_device_count() < 1:
+            raise GpisError("no HIP device: gpismap_amd has no CPU fallback")
+        self.h = C.c_void_p(self.L.gpis3_create(C.byref(_cam(cam6)) if cam6 is not None else None))
+        if not self.h:
+            raise GpisError("gpis3_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpis3_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(self.L.gpis3_reset(self.h), "gpis3_reset")
+
+    def set_camera(self, cam6):
+        _check(self.L.gpis3_set_camera(self.h, C.byref(_cam(cam6))), "gpis3_set_camera")
+
+    def update(self, depth, pose):
+        depth = np.ascontiguousarray(depth, dtype=np.float32)
+        pose = np.ascontiguousarray(pose, dtype=np.float32)
+        if pose.size != 12:
+            raise GpisError("pose must have 12 elements")
+        _check(self.L.gpis3_update(self.h, _p(depth), depth.size, _p(pose)), "gpis3_update")
+
+    def test(self, x, res=None):
+        """x: [N,3] float32.  Returns res [N,8] (zero pre-filled like the mex gateway) or None
+        where the reference's test() returns false."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if res is None:
+            res = np.zeros((x.shape[0], 8), dtype=np.float32)
+        rc = self.L.gpis3_test(self.h, _p(x), 3, x.shape[0], _p(res))
+        if rc == -1:
+            return None
+        _check(rc, "gpis3_test")
+        return res
+
+    def test_device(self, d_x_ptr, n, d_res_ptr, stream=0):
+        _check(self.L.gpis3_test_device(self.h, C.c_void_p(d_x_ptr), n, C.c_void_p(d_res_ptr), C.c_void_p(stream)),
+               "gpis3_test_device")
+
+    def num_points(self):
+        return self.L.gpis3_num_points(self.h)
+
+    def get_all_points(self):
+        n = self.L.gpis3_get_points(self.h, None, 0)
+        out = np.zeros((n, 3), dtype=np.float32)
+        if n:
+            self.L.gpis3_get_points(self.h, _p(out), n)
+        return out
+
+    def nodes(self):
+        n = self.L.gpis3_get_nodes(self.h, None, 0)
+        out = np.zeros((n, 9), dtype=np.float32)
+        if n:
+            self.L.gpis3_get_nodes(self.h, _p(out), n)
+        return out
+
+    def stats(self):
+        a = (C.c_double * 8)()
+        _check(self.L.gpis3_stats(self.h, a, 8), "gpis3_stats")
+        return dict(zip(self.STAT_KEYS, list(a)))
+
+    def set_profile(self, on=True):
+        _check(self.L.gpis3_set_profile(self.h, int(on)), "gpis3_set_profile")
+
+
+class ObsGP:
+    """Kernel-level K1/K2: device-resident observation GP."""
+
+    def __init__(self):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.gpis_obsgp_create())
+        if not self.h:
+            raise GpisError("gpis_obsgp_create failed (no HIP device?)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpis_obsgp_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def train2d(self, vu, f, ni, nj):
+        vu = np.ascontiguousarray(vu, dtype=np.float32)
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        _check(self.L.gpis_obsgp_train2d(self.h, _p(vu), _p(f), ni, nj), "gpis_obsgp_train2d")
+
+    def train1d(self, theta, f):
+        theta = np.ascontiguousarray(theta, dtype=np.float32)
+        f = np.ascontiguousarray(f, dtype=np.float32)
+        _check(self.L.gpis_obsgp_train1d(self.h, _p(theta), _p(f), theta.size), "gpis_obsgp_train1d")
+
+    def query(self, q, val0=0.0):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        n = q.shape[0]
+        val = np.full(n, val0, dtype=np.float32)
+        var = np.zeros(n, dtype=np.float32)
+        _check(self.L.gpis_obsgp_query(self.h, _p(q), n, _p(val), _p(var)), "gpis_obsgp_query")
+        return val, var
+
+    def num_groups(self):
+        return self.L.gpis_obsgp_num_groups(self.h)
+
+    def group(self, g):
+        n = C.c_int(0)
+        x = np.zeros((64, 2), dtype=np.float32)
+        alpha = np.zeros(64, dtype=np.float32)
+        L = np.zeros((64, 64), dtype=np.float32)  # column-major on the device: L[c, r]
+        _check(self.L.gpis_obsgp_get_group(self.h, g, C.byref(n), _p(x), _p(alpha), _p(L)), "gpis_obsgp_get_group")
+        return n.value, x, alpha, L.T.copy()
+
+
+class OnGPIS:
+    """Kernel-level K6/K3/K4: batched cluster training and prediction."""
+
+    def __init__(self, dim, scale):
+        self.L = lib()
+        self.dim = dim
+        self.h = C.c_void_p(self.L.gpis_ongpis_create(dim, float(scale)))
+        if not self.h:
+            raise GpisError("gpis_ongpis_create failed (no HIP device?)")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpis_ongpis_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def train(self, points9, off, ids):
+        """points9: [9, npts] SoA; off: [ncl+1]; ids: concatenated point ids.  Returns model slots."""
+        points9 = np.ascontiguousarray(points9, dtype=np.float32)
+        off = np.ascontiguousarray(off, dtype=np.int32)
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        ncl = off.size - 1
+        models = np.zeros(ncl, dtype=np.int32)
+        _check(self.L.gpis_ongpis_train(self.h, _p(points9), points9.shape[1], _p(off, C.c_int), _p(ids, C.c_int), ncl,
+                                        _p(models, C.c_int)), "gpis_ongpis_train")
+        return models
+
+    def model(self, slot):
+        d = np.zeros(4, dtype=np.int32)
+        _check(self.L.gpis_ongpis_model_dims(self.h, int(slot), _p(d, C.c_int)), "gpis_ongpis_model_dims")
+        N, ng, K, ld = [int(v) for v in d]
+        Lm = np.zeros((ld, ld), dtype=np.float32)
+        alpha = np.zeros(K, dtype=np.float32)
+        gidx = np.zeros(N, dtype=np.int32)
+        _check(self.L.gpis_ongpis_get_model(self.h, int(slot), _p(Lm), _p(alpha), _p(gidx, C.c_int)), "gpis_ongpis_get_model")
+        return dict(N=N, ng=ng, K=K, ld=ld, L=Lm.T.copy(), alpha=alpha, gidx=gidx)  # L[r, c]
+
+    def eval(self, xq, job_q, job_model):
+        xq = np.ascontiguousarray(xq, dtype=np.float32)
+        job_q = np.ascontiguousarray(job_q, dtype=np.int32)
+        job_model = np.ascontiguousarray(job_model, dtype=np.int32)
+        out = np.zeros((job_q.size, 8), dtype=np.float32)
+        _check(self.L.gpis_ongpis_eval(self.h, _p(xq), xq.shape[0], _p(job_q, C.c_int), _p(job_model, C.c_int), job_q.size,
+                                       _p(out)), "gpis_ongpis_eval")
+        return out
+
+    def last_ms(self):
+        a, b = C.c_float(0), C.c_float(0)
+        self.L.gpis_ongpis_last_ms(self.h, C.byref(a), C.byref(b))
+        return a.value, b.value

@@ -1,0 +1,191 @@
+// C-ABI (include/gpismap_amd.h) over the C++ classes.  Nothing throws across it.
+#include <cstring>
+#include <new>
+#include <vector>
+#include "../../include/GPisMap3.h"
+#include "../../include/gpismap_amd.h"
+#include "map_query.h"
+#include "obsgp.h"
+#include "ongpis.h"
+
+using namespace gpis;
+
+// accessors implemented in gpismap3.cpp
+void gpis3_impl_stats(GPisMap3* m, double* out, int n);
+void gpis3_impl_profile(GPisMap3* m, int on);
+
+extern "C" {
+
+int gpis_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+const char* gpis_version(void) { return "gpismap_amd 0.1 (gfx950)"; }
+
+// ---- 3-D map ----------------------------------------------------------------
+void* gpis3_create(const gpis_cam* cam) {
+    try {
+        GPisMap3Param p;
+        if (cam) { camParam c(cam->fx, cam->fy, cam->cx, cam->cy, (float)cam->width, (float)cam->height); return new GPisMap3(p, c); }
+        return new GPisMap3(p);
+    } catch (...) { return nullptr; }
+}
+void gpis3_destroy(void* m) { delete (GPisMap3*)m; }
+int gpis3_reset(void* m) { if (!m) return GPIS_ERR_ARG; ((GPisMap3*)m)->reset(); return GPIS_OK; }
+int gpis3_set_camera(void* m, const gpis_cam* cam) {
+    if (!m || !cam) return GPIS_ERR_ARG;
+    camParam c(cam->fx, cam->fy, cam->cx, cam->cy, (float)cam->width, (float)cam->height);
+    ((GPisMap3*)m)->resetCam(c);
+    return GPIS_OK;
+}
+int gpis3_update(void* m, const float* depth, int n, const float* pose12) {
+    if (!m || !depth || !pose12) return GPIS_ERR_ARG;
+    if (gpis_device_count() < 1) return GPIS_ERR_HIP;
+    try {
+        std::vector<float> pose(pose12, pose12 + 12);
+        ((GPisMap3*)m)->update(const_cast<float*>(depth), n, pose);
+    } catch (...) { return GPIS_ERR_STATE; }
+    return GPIS_OK;
+}
+int gpis3_test(void* m, const float* x, int dim, int n, float* res) {
+    if (!m) return GPIS_ERR_ARG;
+    if (gpis_device_count() < 1) return GPIS_ERR_HIP;
+    try { return ((GPisMap3*)m)->test(const_cast<float*>(x), dim, n, res) ? GPIS_OK : GPIS_ERR_ARG; }
+    catch (...) { return GPIS_ERR_STATE; }
+}
+int gpis3_test_device(void* m, const float* d_x, int n, float* d_res, void* stream) {
+    if (!m) return GPIS_ERR_ARG;
+    try { return ((GPisMap3*)m)->testDevice(d_x, n, d_res, stream) ? GPIS_OK : GPIS_ERR_ARG; }
+    catch (...) { return GPIS_ERR_STATE; }
+}
+int gpis3_num_points(void* m) {
+    if (!m) return GPIS_ERR_ARG;
+    std::vector<float> p; ((GPisMap3*)m)->getAllPoints(p); return (int)(p.size() / 3);
+}
+int gpis3_get_points(void* m, float* out, int cap) {
+    if (!m) return GPIS_ERR_ARG;
+    std::vector<float> p; ((GPisMap3*)m)->getAllPoints(p);
+    int n = (int)(p.size() / 3);
+    if (out && n <= cap && n > 0) std::memcpy(out, p.data(), p.size() * sizeof(float));
+    return n;
+}
+int gpis3_get_nodes(void* m, float* out, int cap) {
+    if (!m) return GPIS_ERR_ARG;
+    std::vector<float> p; ((GPisMap3*)m)->getAllNodes(p);
+    int n = (int)(p.size() / 9);
+    if (out && n <= cap && n > 0) std::memcpy(out, p.data(), p.size() * sizeof(float));
+    return n;
+}
+int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis3_impl_stats((GPisMap3*)m, out, n); return GPIS_OK; }
+int gpis3_set_profile(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_profile((GPisMap3*)m, on); return GPIS_OK; }
+
+// ---- ObsGP --------------------------------------------------------------------
+struct ObsHandle { ObsGPDevice g; hipStream_t s = nullptr; };
+void* gpis_obsgp_create(void) {
+    if (gpis_device_count() < 1) { fprintf(stderr, "[gpismap_amd] no HIP device\n"); return nullptr; }
+    ObsHandle* h = new (std::nothrow) ObsHandle();
+    if (h && hipStreamCreate(&h->s) != hipSuccess) { delete h; return nullptr; }
+    return h;
+}
+void gpis_obsgp_destroy(void* g) { if (!g) return; ObsHandle* h = (ObsHandle*)g; if (h->s) (void)hipStreamDestroy(h->s); delete h; }
+int gpis_obsgp_train2d(void* g, const float* vu, const float* f, int ni, int nj) {
+    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.train2d(vu, f, ni, nj, h->s);
+}
+int gpis_obsgp_train1d(void* g, const float* th, const float* f, int n) {
+    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.train1d(th, f, n, h->s);
+}
+int gpis_obsgp_query(void* g, const float* q, int nq, float* val, float* var) {
+    if (!g || !q || !val || !var) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.query(q, nq, val, var, h->s);
+}
+int gpis_obsgp_num_groups(void* g) { if (!g) return GPIS_ERR_ARG; return ((ObsHandle*)g)->g.ngroups(); }
+int gpis_obsgp_get_group(void* g, int group, int* n, float* x, float* alpha, float* L) {
+    if (!g || !n) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.get_group(group, n, x, alpha, L, h->s);
+}
+
+// ---- OnGPIS -------------------------------------------------------------------
+struct OnHandle {
+    OnGPISStore st; hipStream_t s = nullptr;
+    float* d_xq = nullptr; float* d_out = nullptr; size_t cap_xq = 0, cap_out = 0;
+    OnHandle(int dim, float scale) : st(dim, scale) {}
+};
+void* gpis_ongpis_create(int dim, float scale) {
+    if (dim != 2 && dim != 3) return nullptr;
+    if (gpis_device_count() < 1) { fprintf(stderr, "[gpismap_amd] no HIP device\n"); return nullptr; }
+    OnHandle* h = new (std::nothrow) OnHandle(dim, scale);
+    if (h && hipStreamCreate(&h->s) != hipSuccess) { delete h; return nullptr; }
+    if (h) h->st.profile = true;
+    return h;
+}
+void gpis_ongpis_destroy(void* s) {
+    if (!s) return; OnHandle* h = (OnHandle*)s;
+    (void)hipFree(h->d_xq); (void)hipFree(h->d_out);
+    if (h->s) (void)hipStreamDestroy(h->s);
+    delete h;
+}
+int gpis_ongpis_train(void* s, const float* soa9, int npts, const int* off, const int* ids, int ncl, int* model_out) {
+    if (!s || !soa9 || !off || !ids || ncl < 0) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    int dim = h->st.dim();
+    int rc = h->st.upload_points(soa9, npts, h->s);
+    if (rc) return rc;
+    std::vector<TrainJob> jobs;
+    std::vector<int> idv(ids, ids + off[ncl]);
+    for (int c = 0; c < ncl; ++c) {
+        TrainJob j; j.model = h->st.new_slot(); j.off = off[c]; j.n = off[c + 1] - off[c]; j.ng = 0;
+        for (int k = j.off; k < j.off + j.n; ++k) {
+            int id = ids[k];
+            if (id < 0 || id >= npts) return GPIS_ERR_ARG;
+            bool tiny = true;
+            for (int d = 0; d < dim; ++d) tiny = tiny && ((double)fabsf(soa9[(size_t)(3 + d) * npts + id]) < 1e-6);
+            if (!(((double)soa9[(size_t)8 * npts + id] > 0.1001) || tiny)) ++j.ng;
+        }
+        if (model_out) model_out[c] = j.model;
+        jobs.push_back(j);
+    }
+    return h->st.train_batch(jobs, idv, h->s);
+}
+int gpis_ongpis_model_dims(void* s, int model, int* d4) {
+    if (!s || !d4) return GPIS_ERR_ARG;
+    const ClusterModel* m = ((OnHandle*)s)->st.model(model);
+    if (!m || !m->base) return GPIS_ERR_ARG;
+    d4[0] = m->N; d4[1] = m->ng; d4[2] = m->K; d4[3] = m->ld;
+    return GPIS_OK;
+}
+int gpis_ongpis_get_model(void* s, int model, float* L, float* alpha, int* gidx) {
+    if (!s) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    const ClusterModel* m = h->st.model(model);
+    if (!m || !m->base) return GPIS_ERR_ARG;
+    if (L) GPIS_HIP(hipMemcpyAsync(L, m->L, sizeof(float) * (size_t)m->ld * m->ld, hipMemcpyDeviceToHost, h->s));
+    if (alpha) GPIS_HIP(hipMemcpyAsync(alpha, m->alpha, sizeof(float) * m->K, hipMemcpyDeviceToHost, h->s));
+    if (gidx) GPIS_HIP(hipMemcpyAsync(gidx, m->gidx, sizeof(int) * m->N, hipMemcpyDeviceToHost, h->s));
+    GPIS_HIP(hipStreamSynchronize(h->s));
+    return GPIS_OK;
+}
+int gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs, float* out8) {
+    if (!s || !xq || !job_q || !job_model || !out8 || nq < 1 || njobs < 1) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    int dim = h->st.dim();
+    std::vector<float> x4((size_t)4 * nq, 0.f);
+    for (int i = 0; i < nq; ++i) for (int d = 0; d < dim; ++d) x4[(size_t)4 * i + d] = xq[(size_t)dim * i + d];
+    if (x4.size() > h->cap_xq) { (void)hipFree(h->d_xq); h->d_xq = nullptr; GPIS_HIP(hipMalloc(&h->d_xq, sizeof(float) * x4.size())); h->cap_xq = x4.size(); }
+    size_t no = (size_t)8 * njobs;
+    if (no > h->cap_out) { (void)hipFree(h->d_out); h->d_out = nullptr; GPIS_HIP(hipMalloc(&h->d_out, sizeof(float) * no)); h->cap_out = no; }
+    GPIS_HIP(hipMemcpyAsync(h->d_xq, x4.data(), sizeof(float) * x4.size(), hipMemcpyHostToDevice, h->s));
+    GPIS_HIP(hipMemsetAsync(h->d_out, 0, sizeof(float) * no, h->s));
+    int rc = h->st.eval_jobs(h->d_xq, job_q, job_model, njobs, h->d_out, h->s);
+    if (rc) return rc;
+    GPIS_HIP(hipMemcpyAsync(out8, h->d_out, sizeof(float) * no, hipMemcpyDeviceToHost, h->s));
+    GPIS_HIP(hipStreamSynchronize(h->s));
+    return GPIS_OK;
+}
+int gpis_ongpis_last_ms(void* s, float* t, float* e) {
+    if (!s) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    if (t) *t = h->st.last_train_ms;
+    if (e) *e = h->st.last_eval_ms;
+    return GPIS_OK;
+}
+
+}  // extern "C"

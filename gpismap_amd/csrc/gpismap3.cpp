@@ -1,0 +1,660 @@
+// GPisMap3: MI355X-native drop-in for reference cpp/src/GPisMap3.cpp.
+//
+// The reference interleaves single-point ObsGP queries with octree mutations
+// (evalPoints :580-696, reEvalPoints :321-569).  The observation GP is frozen
+// for the whole frame, so every query is a pure function of the point being
+// processed: here they are evaluated SPECULATIVELY in batches on the GPU (K2)
+// and the tree mutations are replayed on the host in the reference's order.
+// Points that move into a not-yet-visited cluster during the pass (the reference
+// re-evaluates them because it fetches each cluster's node list lazily, :308-311)
+// are handled by an on-demand batch when that cluster is reached.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include "../../include/GPisMap3.h"
+#include "flat_tree.h"
+#include "map_query.h"
+#include "obsgp.h"
+#include "ongpis.h"
+
+using namespace gpis;
+
+namespace {
+
+inline float occ_test(float rinv, float rinv0, float a) {  // GPisMap3.cpp:38-41
+    return (float)(2.0 * (1.0 / (1.0 + std::exp((double)(-a * (rinv - rinv0)))) - 0.5));
+}
+inline float saturate(float v, float lo, float hi) { return std::min(std::max(v, lo), hi); }
+
+std::array<float, 9> quat2dcm(const float q[4]) {  // GPisMap3.cpp:48-63
+    std::array<float, 9> d;
+    d[0] = q[0] * q[0] + q[1] * q[1] - q[2] * q[2] - q[3] * q[3];
+    d[1] = (float)(2.0 * (double)(q[1] * q[2] + q[0] * q[3]));
+    d[2] = (float)(2.0 * (double)(q[1] * q[3] - q[0] * q[2]));
+    d[3] = (float)(2.0 * (double)(q[1] * q[2] - q[0] * q[3]));
+    d[4] = q[0] * q[0] - q[1] * q[1] + q[2] * q[2] - q[3] * q[3];
+    d[5] = (float)(2.0 * (double)(q[0] * q[1] + q[2] * q[3]));
+    d[6] = (float)(2.0 * (double)(q[1] * q[3] + q[0] * q[2]));
+    d[7] = (float)(2.0 * (double)(q[2] * q[3] - q[0] * q[1]));
+    d[8] = q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3];
+    return d;
+}
+
+constexpr float kRtimes = 2.0f;    // params.h:39 GPISMAP3_RTIMES
+constexpr float kCleng = 0.025f;   // params.h:40 GPISMAP3_TREE_CLUSTER_HALF_LENGTH
+
+FlatTreeParam tree_param3() {
+    FlatTreeParam p;
+    p.min_half = (float)(0.0125 / 2.0);  // params.h:41
+    p.max_half = (float)1.6;
+    p.init_half = (float)0.4;
+    p.cluster_half = kCleng;
+    p.min_half_sq = p.min_half * p.min_half;
+    p.cluster_eps = 1e-6;
+    p.qleaf_eps_plain = 0.0001;
+    p.qleaf_eps_dist = 0.001;
+    p.qdesc_eps = 0.001;
+    return p;
+}
+
+}  // namespace
+
+struct GPisMap3::Impl {
+    using T3 = FlatTree<3>;
+    GPisMap3Param setting;
+    camParam cam;
+    T3 tree;
+    T3::Set activeSet;
+    ObsGPDevice gpo;
+    OnGPISStore store;
+    MapQuery mq;
+    hipStream_t stream = nullptr;
+    bool ok = false;        // device objects usable
+    bool has_tree = false;  // reference: t != 0
+    bool gpo_created = false;
+
+    float u_obs_limit[2] = {0, 0}, v_obs_limit[2] = {0, 0};
+    std::vector<float> vu_grid, obs_zinv, obs_valid_u, obs_valid_v, obs_valid_xyzlocal, obs_valid_xyzglobal;
+    float pose_tr[3] = {0, 0, 0}, pose_R[9] = {0};
+    int obs_numdata = 0;
+    float range_obs_max = 0.f;
+
+    // host<->device staging for test()
+    float* d_x = nullptr; float* d_res = nullptr; size_t cap_x = 0, cap_res = 0;
+
+    // statistics
+    long stat_obs_queries = 0, stat_clusters_trained = 0, stat_late = 0;
+    float last_update_ms[6] = {0, 0, 0, 0, 0, 0};
+
+    Impl(const GPisMap3Param& par, const camParam& c)
+        : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
+          mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
+        ok = (hipStreamCreate(&stream) == hipSuccess);
+        if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
+    }
+    ~Impl() {
+        (void)hipFree(d_x); (void)hipFree(d_res);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    void reset() {  // GPisMap3.cpp:99-115
+        tree.clear(); has_tree = false;
+        store.clear();
+        gpo.reset_trained(); gpo_created = false;
+        obs_numdata = 0;
+        activeSet.clear();
+        std::vector<ClusterEntry> none;
+        mq.set_clusters(none, 2.0 * kCleng, stream);
+    }
+
+    bool preprocData(const float* dataz, int N, const std::vector<float>& pose);
+    bool regressObs();
+    void updateMapPoints();
+    void evalPoints();
+    void updateGPs();
+    int try_insert(int pid, T3::Set& ins);
+
+    struct Stage2 {   // per point, after the centre query
+        bool go = false;        // survives the var / occupancy gates
+        float x_new[3], abs_oc = 0.f;
+        float grad_loc[3];
+    };
+    void reeval_batch(const std::vector<int>& ids, std::vector<Stage2>& st, std::vector<float>& pval,
+                      std::vector<float>& pvar);
+    void reeval_apply(int pid, const Stage2& st, const float* pval, const float* pvar);
+};
+
+// ------------------------------------------------------------------ preprocess ----
+bool GPisMap3::Impl::preprocData(const float* dataz, int N, const std::vector<float>& pose) {  // :125-216
+    if (!dataz || N < 1) return false;
+    obs_valid_xyzlocal.clear(); obs_valid_xyzglobal.clear();
+    obs_valid_u.clear(); obs_valid_v.clear(); obs_zinv.clear();
+    range_obs_max = 0.0f;
+    if (pose.size() != 12) return false;
+    for (int i = 0; i < 3; ++i) pose_tr[i] = pose[i];
+    for (int i = 0; i < 9; ++i) pose_R[i] = pose[3 + i];
+    int n = cam.width / setting.obs_skip;
+    int m = cam.height / setting.obs_skip;
+    if (vu_grid.empty()) {
+        if (cam.width * cam.height != N) return false;
+        vu_grid.resize((size_t)2 * n * m);
+        int col = 0, row = 0;
+        for (int n_ = 0; n_ < n; ++n_) {
+            col = n_ * setting.obs_skip;
+            for (int m_ = 0; m_ < m; ++m_) {
+                row = m_ * setting.obs_skip;
+                int j = 2 * (m * n_ + m_);
+                vu_grid[j] = ((float)row - cam.cy) / cam.fy;
+                vu_grid[j + 1] = ((float)col - cam.cx) / cam.fx;
+            }
+        }
+        u_obs_limit[0] = -cam.cx / cam.fx;
+        u_obs_limit[1] = ((float)col - cam.cx) / cam.fx;
+        v_obs_limit[0] = -cam.cy / cam.fy;
+        v_obs_limit[1] = ((float)row - cam.cy) / cam.fy;
+    }
+    obs_numdata = 0;
+    for (int n_ = 0; n_ < n; ++n_) {
+        int col = n_ * setting.obs_skip;
+        for (int m_ = 0; m_ < m; ++m_) {
+            int row = m_ * setting.obs_skip;
+            int k = col * cam.height + row;
+            if (k < N && (double)dataz[k] < 4e0 && (double)dataz[k] > 4e-1) {  // isRangeValid :33-36
+                int j = 2 * (m * n_ + m_);
+                float z = dataz[k];
+                if (range_obs_max < z) range_obs_max = z;
+                obs_zinv.push_back((float)(1.0 / (double)z));
+                float u = vu_grid[j + 1], v = vu_grid[j];
+                obs_valid_u.push_back(u); obs_valid_v.push_back(v);
+                float xloc = u * z, yloc = v * z;
+                obs_valid_xyzlocal.push_back(xloc); obs_valid_xyzlocal.push_back(yloc); obs_valid_xyzlocal.push_back(z);
+                obs_valid_xyzglobal.push_back(pose_R[0] * xloc + pose_R[3] * yloc + pose_R[6] * z + pose_tr[0]);
+                obs_valid_xyzglobal.push_back(pose_R[1] * xloc + pose_R[4] * yloc + pose_R[7] * z + pose_tr[1]);
+                obs_valid_xyzglobal.push_back(pose_R[2] * xloc + pose_R[5] * yloc + pose_R[8] * z + pose_tr[2]);
+                ++obs_numdata;
+            } else obs_zinv.push_back(-1.0f);
+        }
+    }
+    return obs_numdata > 1;
+}
+
+bool GPisMap3::Impl::regressObs() {  // :239-256 -> K1
+    gpo_created = true;
+    if (2 * obs_zinv.size() != vu_grid.size()) return false;
+    int ni = cam.height / setting.obs_skip, nj = cam.width / setting.obs_skip;
+    int rc = gpo.train2d(vu_grid.data(), obs_zinv.data(), ni, nj, stream);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP training failed (%d)\n", rc); return false; }
+    return gpo.trained();
+}
+
+// GPisMap3.cpp:544-556 / :611-623.  Returns 2 when the point was stored and a cluster cell was
+// reported (the caller then fills in its data), 1 when it was stored through the set-less
+// root-growth path (octree.cpp:151-212: it stays in the tree with default data, as in the
+// reference), 0 when it was not stored (the point object is released).
+int GPisMap3::Impl::try_insert(int pid, T3::Set& ins) {
+    bool ok_ = false;
+    if (!tree.is_not_new(tree.root, tree.pts[pid].pos)) {
+        ok_ = tree.insert(tree.root, pid, &ins);
+        if (ok_ && !tree.is_root(tree.root)) tree.root = tree.get_root(tree.root);
+    }
+    if (!ok_) { tree.drop_point(pid); return 0; }
+    return ins.empty() ? 1 : 2;
+}
+
+// ----------------------------------------------------------- re-evaluation ----
+// Stage 1+2 for a batch of existing points: centre query (K2), gates, the (query-free)
+// line search, then the six perturbation queries (K2).  GPisMap3.cpp:334-446.
+void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage2>& st, std::vector<float>& pval,
+                                  std::vector<float>& pvar) {
+    const int n = (int)ids.size();
+    st.assign(n, Stage2());
+    pval.assign((size_t)6 * n, 0.f); pvar.assign((size_t)6 * n, 1e6f);
+    if (n == 0) return;
+    std::vector<float> q((size_t)2 * n), val(n, 0.f), var(n, 1e6f);
+    std::vector<char> front(n, 0);
+    std::vector<std::array<float, 3>> loc(n);
+    for (int i = 0; i < n; ++i) {
+        const float* pos = tree.pts[ids[i]].pos;
+        float x_loc = pose_R[0] * (pos[0] - pose_tr[0]) + pose_R[1] * (pos[1] - pose_tr[1]) + pose_R[2] * (pos[2] - pose_tr[2]);
+        float y_loc = pose_R[3] * (pos[0] - pose_tr[0]) + pose_R[4] * (pos[1] - pose_tr[1]) + pose_R[5] * (pos[2] - pose_tr[2]);
+        float z_loc = pose_R[6] * (pos[0] - pose_tr[0]) + pose_R[7] * (pos[1] - pose_tr[1]) + pose_R[8] * (pos[2] - pose_tr[2]);
+        loc[i] = {x_loc, y_loc, z_loc};
+        front[i] = !(z_loc < 0.0);
+        q[2 * i] = front[i] ? y_loc / z_loc : 1e30f;  // behind the camera: never queried by the reference
+        q[2 * i + 1] = front[i] ? x_loc / z_loc : 1e30f;
+    }
+    int rc = gpo.query(q.data(), n, val.data(), var.data(), stream);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); return; }
+    stat_obs_queries += n;
+    const float delx = setting.delx;
+    std::vector<float> q2((size_t)12 * n, 1e30f);
+    for (int i = 0; i < n; ++i) {
+        if (!front[i]) continue;
+        if (var[i] > setting.obs_var_thre) continue;
+        float x_loc = loc[i][0], y_loc = loc[i][1], z_loc = loc[i][2];
+        float rinv = (float)(1.0 / (double)z_loc);
+        float rinv0 = val[i];
+        float oc = occ_test(rinv, rinv0, (float)((double)z_loc * 30.0));
+        if ((double)oc < -0.02) continue;
+        Stage2& s = st[i];
+        const float* grad = tree.pts[ids[i]].grad;
+        s.grad_loc[0] = pose_R[0] * grad[0] + pose_R[1] * grad[1] + pose_R[2] * grad[2];
+        s.grad_loc[1] = pose_R[3] * grad[0] + pose_R[4] * grad[1] + pose_R[5] * grad[2];
+        s.grad_loc[2] = pose_R[6] * grad[0] + pose_R[7] * grad[1] + pose_R[8] * grad[2];
+        float abs_oc = (float)std::fabs((double)oc);
+        float dx = delx;
+        float x_new[3] = {x_loc, y_loc, z_loc};
+        for (int it = 0; it < 10 && (double)abs_oc > 0.02; ++it) {
+            if (oc < 0) for (int d = 0; d < 3; ++d) x_new[d] += s.grad_loc[d] * dx;
+            else for (int d = 0; d < 3; ++d) x_new[d] -= s.grad_loc[d] * dx;
+            // The reference re-queries the ORIGINAL location (:390-393): same input, same
+            // (rinv0, var) -- no new query is needed and var <= thre still holds.
+            float r_new = z_loc;
+            float oc_new = occ_test((float)(1.0 / (double)r_new), rinv0, (float)((double)r_new * 30.0));
+            float abs_oc_new = (float)std::fabs((double)oc_new);
+            if ((double)abs_oc_new < 0.02 || (double)oc < -0.02) break;
+            else if ((double)(oc * oc_new) < 0.0) dx = (float)(0.5 * (double)dx);
+            else dx = (float)(1.1 * (double)dx);
+            abs_oc = abs_oc_new;
+            oc = oc_new;
+        }
+        s.go = true; s.abs_oc = abs_oc;
+        for (int d = 0; d < 3; ++d) s.x_new[d] = x_new[d];
+        static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
+        for (int k = 0; k < 6; ++k) {
+            float X = x_new[0] + delx * pert[0][k];
+            float Y = x_new[1] + delx * pert[1][k];
+            float Z = x_new[2] + delx * pert[2][k];
+            q2[(size_t)12 * i + 2 * k] = Y / Z;
+            q2[(size_t)12 * i + 2 * k + 1] = X / Z;
+        }
+    }
+    rc = gpo.query(q2.data(), 6 * n, pval.data(), pvar.data(), stream);
+    if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc);
+    stat_obs_queries += 6 * (long)n;
+}
+
+// Stage 3 for one point: fusion + tree mutation, in the reference's order.  :410-566
+void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, const float* pvar) {
+    if (!s.go) return;
+    const float w = (float)(1.0 / 6.0);
+    const float delx = setting.delx;
+    static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
+    float occ[6] = {-1, -1, -1, -1, -1, -1};
+    float occ_mean = 0.f, r0_mean = 0.f, r0_sqr_sum = 0.f;
+    float r_new = s.x_new[2];
+    float var = 0.f;
+    for (int i = 0; i < 6; ++i) {
+        float Z = s.x_new[2] + delx * pert[2][i];
+        r_new = Z;
+        var = pvar[i];
+        if (var > setting.obs_var_thre) break;
+        float rinv0 = pval[i];
+        occ[i] = occ_test((float)(1.0 / (double)r_new), rinv0, (float)((double)r_new * 30.0));
+        occ_mean += w * occ[i];
+        float r0 = (float)(1.0 / (double)rinv0);
+        r0_sqr_sum += r0 * r0;
+        r0_mean += w * r0;
+    }
+    if (var > setting.obs_var_thre) return;
+
+    FlatPoint<3> nd = tree.pts[pid];  // copy: the point object is replaced below
+    const float* pos = nd.pos;
+    const float* grad = nd.grad;
+    float gl[3] = {(occ[0] - occ[1]) / delx, (occ[2] - occ[3]) / delx, (occ[4] - occ[5]) / delx};
+    float norm_g = std::sqrt(gl[0] * gl[0] + gl[1] * gl[1] + gl[2] * gl[2]);
+    if ((double)norm_g < 1e-3) {  // uncertainty increased
+        tree.pts[pid].sigx = (float)(2.0 * (double)nd.sigx);
+        tree.pts[pid].sigg = (float)(2.0 * (double)nd.sigg);
+        return;
+    }
+    float r_var = (float)((double)r0_sqr_sum / 5.0 - (double)(r0_mean * r0_mean) * 6.0 / 5.0);
+    r_var /= delx;
+    float noise = 100.0f, grad_noise = 1.0f;
+    if ((double)norm_g > 1e-6) {
+        for (int d = 0; d < 3; ++d) gl[d] = gl[d] / norm_g;
+        noise = setting.min_position_noise * saturate(r_new * r_new, 1.0f, noise);
+        grad_noise = saturate(std::fabs(occ_mean) + r_var, setting.min_grad_noise, grad_noise);
+    } else noise = setting.min_position_noise * noise;
+    const float* x_new = s.x_new;
+    float dist = std::sqrt(x_new[0] * x_new[0] + x_new[1] * x_new[1] + x_new[2] * x_new[2]);
+    float view_ang = std::max(-(x_new[0] * gl[0] + x_new[1] * gl[1] + x_new[2] * gl[2]) / dist, (float)1e-1);
+    float view_ang2 = view_ang * view_ang;
+    float view_noise = (float)((double)setting.min_position_noise * ((1.0 - (double)view_ang2) / (double)view_ang2));
+    noise += view_noise + s.abs_oc;
+    grad_noise = (float)((double)grad_noise + 0.1 * (double)view_noise);
+
+    float pos_new[3], grad_new[3];
+    for (int d = 0; d < 3; ++d) {
+        pos_new[d] = pose_R[d] * x_new[0] + pose_R[3 + d] * x_new[1] + pose_R[6 + d] * x_new[2] + pose_tr[d];
+        grad_new[d] = pose_R[d] * gl[0] + pose_R[3 + d] * gl[1] + pose_R[6 + d] * gl[2];
+    }
+    float noise_old = nd.sigx, grad_noise_old = nd.sigg;
+    float pos_noise_sum = noise_old + noise;
+    float grad_noise_sum = grad_noise_old + grad_noise;
+    if ((double)grad_noise_old > 0.5 || (double)grad_noise_old > 0.6) {
+        ;
+    } else {
+        for (int d = 0; d < 3; ++d) pos_new[d] = (noise * pos[d] + noise_old * pos_new[d]) / pos_noise_sum;
+        float dist2 = (float)(0.5 * (double)std::sqrt((pos[0] - pos_new[0]) * (pos[0] - pos_new[0]) +
+                                                       (pos[1] - pos_new[1]) * (pos[1] - pos_new[1]) +
+                                                       (pos[2] - pos_new[2]) * (pos[2] - pos_new[2])));
+        float axis[3];
+        axis[0] = grad_new[1] * grad[2] - grad_new[2] * grad[1];
+        axis[1] = -grad_new[0] * grad[2] + grad_new[2] * grad[0];
+        axis[2] = grad_new[0] * grad[1] - grad_new[1] * grad[0];
+        float ang = (float)std::acos((double)(grad_new[0] * grad[0] + grad_new[1] * grad[1] + grad_new[2] * grad[2]));
+        ang = ang * noise / pos_noise_sum;
+        float q[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+        if (ang > 1 - 6) {  // sic, GPisMap3.cpp:517
+            q[0] = (float)std::cos((double)ang / 2.0);
+            float sina = (float)std::sin((double)ang / 2.0);
+            q[1] = axis[0] * sina; q[2] = axis[1] * sina; q[3] = axis[2] * sina;
+        }
+        auto Rot = quat2dcm(q);
+        grad_new[0] = Rot[0] * grad[0] + Rot[1] * grad[1] + Rot[2] * grad[2];
+        grad_new[1] = Rot[3] * grad[0] + Rot[4] * grad[1] + Rot[5] * grad[2];
+        grad_new[2] = Rot[6] * grad[0] + Rot[7] * grad[1] + Rot[8] * grad[2];
+        grad_noise = std::min((float)1.0, std::max(grad_noise * grad_noise_old / grad_noise_sum + dist2, setting.map_noise_param));
+        noise = std::max((noise * noise_old / pos_noise_sum + dist2), setting.map_noise_param);
+    }
+    tree.remove(tree.root, nd.pos, &activeSet);
+    if ((double)noise > 1.0 && (double)grad_noise > 0.61) return;
+    int np = tree.new_point(pos_new);
+    T3::Set ins;
+    if (try_insert(np, ins) != 2) return;
+    FlatPoint<3>& p = tree.pts[np];
+    p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
+    for (int d = 0; d < 3; ++d) p.grad[d] = grad_new[d];
+    for (int c : ins) activeSet.insert(c);
+}
+
+// ------------------------------------------------------------ updateMapPoints ----
+void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
+    if (!has_tree || !gpo_created) return;
+    std::vector<int> oc;
+    tree.query_clusters(tree.root, pose_tr, range_obs_max, oc, nullptr);
+    if (oc.empty()) return;
+    float r2 = range_obs_max * range_obs_max;
+    std::vector<int> sel;  // clusters passing the range / frustum gates, in visiting order
+    for (int c : oc) {
+        const T3::TNode& cn = tree.nodes[c];
+        const float* ct = cn.c;
+        float l = cn.h;
+        float sqr_range = (ct[0] - pose_tr[0]) * (ct[0] - pose_tr[0]) + (ct[1] - pose_tr[1]) * (ct[1] - pose_tr[1]) +
+                          (ct[2] - pose_tr[2]) * (ct[2] - pose_tr[2]);
+        if (sqr_range > (r2 + 2 * l * l)) continue;
+        int within_angle = 0;  // overwritten per corner, not accumulated (:298)
+        for (int i = 0; i < 8; ++i) {
+            float e[3] = {(i & 1) ? cn.hi[0] : cn.lo[0], (i & 2) ? cn.lo[1] : cn.hi[1], (i & 4) ? cn.lo[2] : cn.hi[2]};
+            float x_loc = pose_R[0] * (e[0] - pose_tr[0]) + pose_R[1] * (e[1] - pose_tr[1]) + pose_R[2] * (e[2] - pose_tr[2]);
+            float y_loc = pose_R[3] * (e[0] - pose_tr[0]) + pose_R[4] * (e[1] - pose_tr[1]) + pose_R[5] * (e[2] - pose_tr[2]);
+            float z_loc = pose_R[6] * (e[0] - pose_tr[0]) + pose_R[7] * (e[1] - pose_tr[1]) + pose_R[8] * (e[2] - pose_tr[2]);
+            if (z_loc > 0) {
+                float xv = x_loc / z_loc, yv = y_loc / z_loc;
+                within_angle = int((xv > u_obs_limit[0]) && (xv < u_obs_limit[1]) && (yv > v_obs_limit[0]) && (yv < v_obs_limit[1]));
+            }
+        }
+        if (within_angle == 0) continue;
+        sel.push_back(c);
+    }
+    if (sel.empty()) return;
+
+    // speculative batch over every point currently stored in the selected clusters
+    std::vector<int> ids;
+    for (int c : sel) tree.all_points(c, ids);
+    std::vector<Stage2> st;
+    std::vector<float> pval, pvar;
+    reeval_batch(ids, st, pval, pvar);
+    std::vector<int> slot(tree.pts.size(), -1);
+    for (size_t i = 0; i < ids.size(); ++i) slot[ids[i]] = (int)i;
+
+    // replay in the reference's order; node lists are fetched lazily per cluster (:308-311)
+    std::vector<int> nodes, late;
+    for (int c : sel) {
+        nodes.clear();
+        tree.all_points(c, nodes);
+        late.clear();
+        for (int pid : nodes) if (pid >= (int)slot.size() || slot[pid] < 0) late.push_back(pid);
+        std::vector<Stage2> lst;
+        std::vector<float> lval, lvar;
+        if (!late.empty()) { reeval_batch(late, lst, lval, lvar); stat_late += (long)late.size(); }
+        size_t li = 0;
+        for (int pid : nodes) {
+            if (pid < (int)slot.size() && slot[pid] >= 0) {
+                int i = slot[pid];
+                reeval_apply(pid, st[i], &pval[(size_t)6 * i], &pvar[(size_t)6 * i]);
+            } else {
+                reeval_apply(pid, lst[li], &lval[6 * li], &lvar[6 * li]);
+                ++li;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ evalPoints ----
+void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
+    if (!has_tree || obs_numdata < 1) return;
+    const float w = (float)(1.0 / 6.0);
+    const float delx = setting.delx;
+    const int n = obs_numdata;
+    static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
+    // one speculative K2 batch: centre + 6 perturbations per valid pixel
+    std::vector<float> q((size_t)14 * n), val((size_t)7 * n, 0.f), var((size_t)7 * n, 1e6f);
+    for (int k = 0; k < n; ++k) {
+        const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
+        q[(size_t)14 * k] = obs_valid_v[k];
+        q[(size_t)14 * k + 1] = obs_valid_u[k];
+        for (int i = 0; i < 6; ++i) {
+            float X = xl[0] + delx * pert[0][i];
+            float Y = xl[1] + delx * pert[1][i];
+            float Z = xl[2] + delx * pert[2][i];
+            q[(size_t)14 * k + 2 + 2 * i] = Y / Z;
+            q[(size_t)14 * k + 3 + 2 * i] = X / Z;
+        }
+    }
+    int rc = gpo.query(q.data(), 7 * n, val.data(), var.data(), stream);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); return; }
+    stat_obs_queries += 7 * (long)n;
+
+    for (int k = 0; k < n; ++k) {
+        const float* pv = &val[(size_t)7 * k];
+        const float* pr = &var[(size_t)7 * k];
+        if (pr[0] > setting.obs_var_thre) continue;
+        int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
+        T3::Set ins;
+        if (try_insert(pid, ins) != 2) continue;
+        const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
+        float occ[6] = {-1, -1, -1, -1, -1, -1};
+        float occ_mean = 0.f;
+        float v = pr[0];
+        for (int i = 0; i < 6; ++i) {
+            float Z = xl[2] + delx * pert[2][i];
+            v = pr[1 + i];
+            if (v > setting.obs_var_thre) break;
+            occ[i] = occ_test((float)(1.0 / (double)Z), pv[1 + i], (float)((double)Z * 30.0));
+            occ_mean += w * occ[i];
+        }
+        if (v > setting.obs_var_thre) {
+            tree.remove(tree.root, tree.pts[pid].pos, nullptr);
+            continue;
+        }
+        float noise = 100.0f, grad_noise = 1.00f;
+        float g[3] = {(occ[0] - occ[1]) / delx, (occ[2] - occ[3]) / delx, (occ[4] - occ[5]) / delx};
+        float norm_grad = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+        if ((double)norm_grad > 1e-6) {
+            norm_grad = std::sqrt(norm_grad);
+            float gx = g[0] / norm_grad, gy = g[1] / norm_grad, gz = g[2] / norm_grad;
+            g[0] = pose_R[0] * gx + pose_R[3] * gy + pose_R[6] * gz;
+            g[1] = pose_R[1] * gx + pose_R[4] * gy + pose_R[7] * gz;
+            g[2] = pose_R[2] * gx + pose_R[5] * gy + pose_R[8] * gz;
+            float dist = std::sqrt(xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
+            noise = setting.min_position_noise * saturate(dist, 1.0f, noise);
+            grad_noise = saturate(std::fabs(occ_mean), setting.min_grad_noise, grad_noise);
+            float view_ang = std::max(-(xl[0] * gx + xl[1] * gy + xl[2] * gz) / dist, (float)1e-1);
+            float view_ang2 = view_ang * view_ang;
+            float view_noise = (float)((double)setting.min_position_noise * ((1.0 - (double)view_ang2) / (double)view_ang2));
+            noise += view_noise;
+        }
+        FlatPoint<3>& p = tree.pts[pid];
+        p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
+        for (int d = 0; d < 3; ++d) p.grad[d] = g[d];
+        for (int c : ins) activeSet.insert(c);
+    }
+}
+
+// -------------------------------------------------------------------- updateGPs ----
+void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
+    T3::Set updateSet(activeSet);
+    std::vector<int> qs;
+    for (int a : activeSet) {
+        qs.clear();
+        tree.query_clusters(tree.root, tree.nodes[a].c, kRtimes * tree.nodes[a].h, qs, nullptr);
+        for (int c : qs) updateSet.insert(c);
+    }
+    for (int m : tree.released_models) store.release_slot(m);
+    tree.released_models.clear();
+    if (!updateSet.empty()) {
+        std::vector<int> todo(updateSet.begin(), updateSet.end());
+        std::sort(todo.begin(), todo.end());
+        std::vector<TrainJob> jobs;
+        std::vector<int> ids, res;
+        for (int c : todo) {
+            res.clear();
+            tree.query_range(tree.root, tree.nodes[c].c, tree.nodes[c].h * kRtimes, res);
+            if (res.empty()) continue;
+            int ng = 0;
+            for (int pid : res) {  // OnGPIS.cpp:122-125
+                const FlatPoint<3>& p = tree.pts[pid];
+                bool tiny = ((double)std::fabs(p.grad[0]) < 1e-6) && ((double)std::fabs(p.grad[1]) < 1e-6) && ((double)std::fabs(p.grad[2]) < 1e-6);
+                if (!(((double)p.sigg > 0.1001) || tiny)) ++ng;
+            }
+            if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
+            TrainJob j;
+            j.model = tree.nodes[c].model; j.off = (int)ids.size(); j.n = (int)res.size(); j.ng = ng;
+            jobs.push_back(j);
+            ids.insert(ids.end(), res.begin(), res.end());
+        }
+        if (!jobs.empty()) {
+            // mirror of the map points in HBM: 9 SoA rows indexed by point id
+            size_t np = tree.pts.size();
+            std::vector<float> soa(9 * np, 0.f);
+            for (size_t i = 0; i < np; ++i) {
+                const FlatPoint<3>& p = tree.pts[i];
+                for (int d = 0; d < 3; ++d) { soa[d * np + i] = p.pos[d]; soa[(3 + d) * np + i] = p.grad[d]; }
+                soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
+            }
+            int rc = store.upload_points(soa.data(), (int)np, stream);
+            if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
+            if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc);
+            stat_clusters_trained += (long)jobs.size();
+        }
+    }
+    activeSet.clear();
+
+    // cluster table for test(): every non-empty cluster cell in traversal order
+    std::vector<int> cl;
+    tree.all_clusters(cl);
+    std::vector<ClusterEntry> ent(cl.size());
+    for (size_t i = 0; i < cl.size(); ++i) {
+        const T3::TNode& t = tree.nodes[cl[i]];
+        for (int d = 0; d < 3; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
+        ent[i].model = t.model;
+    }
+    int rc = mq.set_clusters(ent, 2.0 * (double)kCleng, stream);
+    if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
+}
+
+// --------------------------------------------------------------- public surface ----
+GPisMap3::GPisMap3() : p_(new Impl(GPisMap3Param(), camParam())) {}
+GPisMap3::GPisMap3(GPisMap3Param par) : p_(new Impl(par, camParam())) {}
+GPisMap3::GPisMap3(GPisMap3Param par, camParam c) : p_(new Impl(par, c)) {}
+GPisMap3::~GPisMap3() { delete p_; }
+
+void GPisMap3::reset() { p_->reset(); }
+
+void GPisMap3::resetCam(camParam c) {  // GPisMap3.cpp:117-123
+    p_->cam = c;
+    p_->vu_grid.clear();
+}
+
+void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisMap3.cpp:218-237
+    Impl& m = *p_;
+    if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
+    m.tree.recycle();
+    if (!m.preprocData(dataz, N, pose)) return;
+    if (m.regressObs()) {
+        m.updateMapPoints();
+        if (!m.has_tree) {  // addNewMeas :571-578
+            float c[3] = {0.f, 0.f, 0.f};
+            m.tree.make_root(c);
+            m.has_tree = true;
+        }
+        m.evalPoints();
+        m.updateGPs();
+    }
+}
+
+bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) {
+    Impl& m = *p_;
+    if (!m.ok || !d_x || !d_res || leng < 1) return false;
+    if (!m.has_tree) return false;  // the reference dereferences a null tree here
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
+    return m.mq.run(m.store, d_x, leng, d_res, s) == GPIS_OK;
+}
+
+bool GPisMap3::test(float* x, int dim, int leng, float* res) {  // GPisMap3.cpp:904-949
+    Impl& m = *p_;
+    if (x == 0 || dim != 3 || leng < 1) return false;
+    if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::test: HIP device unavailable\n"); return false; }
+    if (!m.has_tree) return false;
+    size_t nx = (size_t)3 * leng, nr = (size_t)8 * leng;
+    if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return false; m.cap_x = nx; }
+    if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return false; m.cap_res = nr; }
+    if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
+    // only some entries are written (callers pre-fill res, mexGPisMap3.cpp:99): start from the caller's buffer
+    if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
+    if (m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream) != GPIS_OK) return false;
+    if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return false;
+    return hipStreamSynchronize(m.stream) == hipSuccess;
+}
+
+void GPisMap3::getAllPoints(std::vector<float>& pos) {  // GPisMap3.cpp:951-972
+    pos.clear();
+    Impl& m = *p_;
+    if (!m.has_tree) return;
+    std::vector<int> ids;
+    m.tree.all_points(m.tree.root, ids);
+    pos.reserve(ids.size() * 3);
+    for (int id : ids) for (int d = 0; d < 3; ++d) pos.push_back(m.tree.pts[id].pos[d]);
+}
+
+void GPisMap3::getAllNodes(std::vector<float>& out) {
+    out.clear();
+    Impl& m = *p_;
+    if (!m.has_tree) return;
+    std::vector<int> ids;
+    m.tree.all_points(m.tree.root, ids);
+    out.reserve(ids.size() * 9);
+    for (int id : ids) {
+        const FlatPoint<3>& p = m.tree.pts[id];
+        for (int d = 0; d < 3; ++d) out.push_back(p.pos[d]);
+        for (int d = 0; d < 3; ++d) out.push_back(p.grad[d]);
+        out.push_back(p.val); out.push_back(p.sigx); out.push_back(p.sigg);
+    }
+}
+
+// accessors used by the C-ABI (capi.cpp)
+void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
+    GPisMap3::Impl& m = *g->impl();
+    double v[8] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+                   (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
+                   (double)m.store.device_bytes()};
+    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+}
+void gpis3_impl_profile(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    m.mq.profile = on != 0;
+    m.store.profile = on != 0;
+}

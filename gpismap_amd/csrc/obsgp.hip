@@ -1,0 +1,192 @@
+// K1 / K2: observation-space GP (Ornstein-Uhlenbeck, <= 64 points per group).
+//
+// Replaces the reference loops
+//   K1  ObsGP2D::trainValidPoints  cpp/src/ObsGP.cpp:280-329  -> GPou::train :32-48
+//       ObsGP1D::train             cpp/src/ObsGP.cpp:85-143
+//       ornstein_uhlenbeck         cpp/src/covFnc.cpp:47-68
+//   K2  ObsGP2D::test_kernel       cpp/src/ObsGP.cpp:352-408  -> GPou::test :50-62
+//       ObsGP1D::test              cpp/src/ObsGP.cpp:145-187
+//       ornstein_uhlenbeck (cross) cpp/src/covFnc.cpp:93-109
+//
+// One 64-lane wavefront owns one group (K1) or one query (K2): lane i owns
+// point i.  K (n x n) is built and factored in LDS; the query path does a
+// column-oriented forward substitution with lane broadcasts.  Summation orders
+// are the fixed chains of dev_common.h, so results are bit-identical to the
+// unblocked CPU order (given equal exp()).
+#include "obsgp.h"
+
+namespace gpis {
+
+static constexpr float OU_SCALE = 0.5f;   // params.h:99  DEFAULT_OBSGP_SCALE_PARAM
+static constexpr float OU_NOISE = 0.01f;  // params.h:100 DEFAULT_OBSGP_NOISE_PARAM
+static constexpr int LDA = 65;            // padded LDS row (conflict-free column walks)
+
+// ---------------------------------------------------------------------------
+// K1.  grid = number of groups, block = 64.
+//   mode 2: group g = (m, n) tile of the (ni x nj) grid; pixels with f > 0 are
+//           compacted in j-outer / i-inner order (ObsGP.cpp:301-310).
+//   mode 1: group g = contiguous range [ga[g], ga[g]+glen[g]) of a 1-D scan.
+// Output per group: n, x[64][2], alpha[64], L[64x64] column-major (ld 64).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void obsgp_train_kernel(ObsGPView v) {
+    __shared__ float A[64 * LDA];
+    __shared__ float xs[64][2];
+    __shared__ float ys[64];
+
+    const int g = blockIdx.x;
+    const int lane = threadIdx.x;
+    int ind = -1;
+    if (v.mode == 2) {
+        int n_ = g % v.ng0, m_ = g / v.ng0;
+        int i0 = v.i0[n_], i1 = v.i1[n_], j0 = v.j0[m_], j1 = v.j1[m_];
+        int wi = i1 - i0 + 1, wj = j1 - j0 + 1;
+        if (lane < wi * wj) ind = (j0 + lane / wi) * v.ni + (i0 + lane % wi);
+    } else {
+        if (lane < v.glen[g]) ind = v.ga[g] + lane;
+    }
+    float f = -1.f, x0 = 0.f, x1 = 0.f;
+    if (ind >= 0) {
+        f = v.f[ind];
+        if (v.mode == 2) { x0 = v.x[2 * ind]; x1 = v.x[2 * ind + 1]; }
+        else x0 = v.x[ind];
+    }
+    bool valid = (ind >= 0) && (v.mode == 1 || f > 0.f);
+    unsigned long long mask = __ballot(valid);
+    const int n = __popcll(mask);
+    int rank = __popcll(mask & ((1ull << lane) - 1ull));
+    if (lane == 0) v.tn[g] = n;
+    if (n == 0) return;
+    if (valid) { xs[rank][0] = x0; xs[rank][1] = x1; ys[rank] = f; }
+    __syncthreads();
+
+    const float a = 1 / OU_SCALE;
+    // lane i builds row i (lower part).  covFnc.cpp:55-64
+    if (lane < n) {
+        float xi0 = xs[lane][0], xi1 = xs[lane][1];
+        for (int j = 0; j < lane; ++j) A[lane * LDA + j] = d_ou_k(d_dist2(xs[j][0], xs[j][1], xi0, xi1), a);
+        A[lane * LDA + lane] = (float)(1.0 + (double)OU_NOISE);
+    }
+    __syncthreads();
+
+    // right-looking Cholesky, one column per step; chain order (O1).
+    for (int j = 0; j < n; ++j) {
+        float d = sqrtf(A[j * LDA + j]);
+        float lij = 0.f;
+        if (lane > j && lane < n) lij = A[lane * LDA + j] / d;
+        __syncthreads();
+        if (lane == j) A[j * LDA + j] = d;
+        if (lane > j && lane < n) A[lane * LDA + j] = lij;
+        __syncthreads();
+        if (lane > j && lane < n) {
+            float nl = -lij;
+            for (int k = j + 1; k <= lane; ++k) A[lane * LDA + k] = fmaf(nl, A[k * LDA + j], A[lane * LDA + k]);
+        }
+        __syncthreads();
+    }
+
+    // alpha = L^-T (L^-1 y).  forward: column oriented, ascending chain.
+    float b = (lane < n) ? ys[lane] : 0.f;
+    for (int k = 0; k < n; ++k) {
+        float t = b / A[lane < n ? lane * LDA + lane : 0];
+        float zk = __shfl(t, k);
+        if (lane == k) b = zk;
+        if (lane > k && lane < n) b = fmaf(A[lane * LDA + k], -zk, b);
+    }
+    // backward: alpha_j = (z_j - sum_{k>j, descending} L_kj alpha_k) / L_jj
+    for (int k = n - 1; k >= 0; --k) {
+        float t = b / A[lane < n ? lane * LDA + lane : 0];
+        float ak = __shfl(t, k);
+        if (lane == k) b = ak;
+        if (lane < k) b = fmaf(-A[k * LDA + lane], ak, b);
+    }
+
+    float* tx = v.tx + (size_t)g * 128;
+    tx[2 * lane] = (lane < n) ? xs[lane][0] : 0.f;
+    tx[2 * lane + 1] = (lane < n) ? xs[lane][1] : 0.f;
+    v.talpha[(size_t)g * 64 + lane] = (lane < n) ? b : 0.f;
+    float* tL = v.tL + (size_t)g * 4096;
+    for (int c = 0; c < 64; ++c) {  // column-major, coalesced per column
+        float val = 0.f;
+        if (lane < n && c <= lane && c < n) val = A[lane * LDA + c];
+        else if (lane == c) val = 1.f;
+        tL[c * 64 + lane] = val;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K2.  One wavefront per query; 4 queries per 256-thread block.
+// Group lookup reproduces ObsGP.cpp:359-406 (2-D) / :154-183 (1-D) exactly.
+// Outputs val (untouched when no group answers) and var (1e6 then).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int obsgp_lookup2(const ObsGPView& v, float q0, float q1) {
+    const float margin = 0.005f;  // params.h:107
+    if (q0 < v.vali[0] + margin) return -1;
+    if (q0 > v.vali[v.ng0] - margin) return -1;
+    if (q1 < v.valj[0] + margin) return -1;
+    if (q1 > v.valj[v.ng1] - margin) return -1;
+    int n = 0;
+    for (int k = 1; k <= v.ng0; ++k, ++n) if (q0 < v.vali[k]) break;
+    int m = 0;
+    for (int k = 1; k <= v.ng1; ++k, ++m) if (q1 < v.valj[k]) break;
+    int gi = m * v.ng0 + n;
+    if (gi < v.ngroups && v.tn[gi] > 0) return gi;
+    return -1;
+}
+__device__ __forceinline__ int obsgp_lookup1(const ObsGPView& v, float q0) {
+    const float margin = 0.0175f;  // params.h:105
+    int nr = v.ngroups + 1;        // range table has ngroups+1 entries
+    float liml = v.vali[0] + margin, limr = v.vali[nr - 1] - margin;
+    if (q0 < liml || q0 > limr) return -1;
+    for (int k = 1; k < nr; ++k)
+        if (q0 > v.vali[k - 1] && q0 < v.vali[k]) return (v.tn[k - 1] > 0) ? k - 1 : -1;
+    return -1;
+}
+
+__global__ __launch_bounds__(256) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
+                                                          float* __restrict__ val, float* __restrict__ var) {
+    const int lane = threadIdx.x & 63;
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qi >= nq) return;
+    float q0, q1 = 0.f;
+    if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
+    else q0 = q[qi];
+    int g = (v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0);
+    g = __builtin_amdgcn_readfirstlane(g);
+    if (g < 0) { if (lane == 0) var[qi] = 1e6f; return; }
+    const int n = v.tn[g];
+    const float a = 1 / OU_SCALE;
+    const float* tx = v.tx + (size_t)g * 128;
+    const float* tL = v.tL + (size_t)g * 4096;
+    float k = 0.f, p = 0.f;
+    if (lane < n) {
+        k = d_ou_k(d_dist2(tx[2 * lane], tx[2 * lane + 1], q0, q1), a);
+        p = k * v.talpha[(size_t)g * 64 + lane];
+    }
+    // mean: 64-slot xor butterfly (order O4)
+    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
+    // variance: forward substitution, chain (O1); acc chain (O5)
+    float acc = 0.f;
+    float col = tL[lane];
+    for (int j = 0; j < n; ++j) {
+        float nxt = (j + 1 < n) ? tL[(j + 1) * 64 + lane] : 0.f;
+        float t = k / col;          // lane j holds k_j / L_jj
+        float vj = __shfl(t, j);
+        if (lane > j) k = fmaf(col, -vj, k);
+        acc = fmaf(vj, vj, acc);
+        col = nxt;
+    }
+    if (lane == 0) {
+        val[qi] = p;
+        var[qi] = (1 + OU_NOISE) - acc;  // ObsGP.cpp:61
+    }
+}
+
+void obsgp_launch_train(const ObsGPView& v, hipStream_t s) {
+    hipLaunchKernelGGL(obsgp_train_kernel, dim3(v.ngroups), dim3(64), 0, s, v);
+}
+void obsgp_launch_query(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s) {
+    if (nq <= 0) return;
+    hipLaunchKernelGGL(obsgp_query_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, d_q, nq, d_val, d_var);
+}
+
+}  // namespace gpis

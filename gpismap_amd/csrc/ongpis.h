@@ -1,0 +1,113 @@
+// Device-resident OnGPIS local regressors (reference cpp/include/OnGPIS.h:38-73):
+// batched training (K6 gather + kernel-matrix build + K3 Cholesky/solve) and
+// batched prediction (K4) over per-cluster models that live in HBM.
+#pragma once
+#include <vector>
+#include "dev_common.h"
+
+namespace gpis {
+
+// One trained cluster model.  All pointers are device pointers into one pooled
+// allocation (`base`).  L is column-major with leading dimension ld (multiple of
+// 32, >= K+1); rows/cols >= K of the padded square carry the identity, so a
+// 32-blocked triangular solve can run over nb = ceil(K/32) full blocks.
+struct ClusterModel {
+    int dim;    // 2 or 3
+    int N;      // training points
+    int ng;     // points with a usable normal
+    int K;      // N + dim*ng
+    int ld;     // leading dimension of L
+    int nb;     // ceil(K / 32)
+    float scale;            // GP length scale
+    float* L;               // [ld*ld] lower Cholesky factor
+    float* alpha;           // [ld]
+    float* x4;              // [N][4]  (x, y, z|0, 0)
+    int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)
+    // training scratch (kept: tiny)
+    float* y;               // [ld]  targets, then z = L^-1 y
+    float* sig;             // [2*N] sigx' (after the 2.0 override), sigg
+    int* gidx;              // [N]   running gradient index or -1
+    void* base;
+};
+
+// Map-point mirror in HBM: structure of arrays, index = stable point id.
+struct PointsSoA {
+    int n = 0, cap = 0;
+    float* d = nullptr;  // [9][cap]: px py pz gx gy gz val sigx sigg (2-D: pz = gz = 0)
+};
+
+struct TrainJob {       // host description of one cluster to (re)train
+    int model;          // slot in the store
+    int off, n;         // range in the concatenated point-id list
+    int ng;             // number of gradient-bearing points (host-computed, OnGPIS.cpp:122-125)
+};
+
+class OnGPISStore {
+public:
+    OnGPISStore(int dim, float scale);
+    ~OnGPISStore();
+    int dim() const { return dim_; }
+    // allocate an empty slot / release it (cluster node destroyed)
+    int new_slot();
+    void release_slot(int slot);
+    void clear();
+    // Upload the point mirror (host SoA rows of length n, 9 rows).
+    int upload_points(const float* soa9, int n, hipStream_t s);
+    // K6 + K3 for a batch of clusters.  ids = concatenated point ids (tree order).
+    int train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s);
+    // Predict: jobs (query index, model slot) evaluated against xq (device, [nq][4]); out
+    // (device) receives 2*(1+dim) floats per job: mean(1+dim), var(1+dim).
+    int eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
+                  hipStream_t s);
+    const ClusterModel* model(int slot) const { return (slot >= 0 && slot < (int)models_.size() && live_[slot]) ? &models_[slot] : nullptr; }
+    ClusterModel* d_models() { return d_models_; }   // device array mirroring models_
+    int sync_models(hipStream_t s);                  // re-upload descriptor table if dirty
+    int num_slots() const { return (int)models_.size(); }
+    size_t device_bytes() const;
+    DevPool* pool() { return pool_; }
+    // timing of the dominant kernels (hipEvents on the launch stream), ms of the last call
+    float last_train_ms = 0.f, last_eval_ms = 0.f;
+    long long last_eval_flops = 0;
+    bool profile = false;
+
+private:
+    int alloc_model(int slot, int N, int ng);
+    int dim_;
+    float scale_;
+    DevPool* pool_;
+    std::vector<ClusterModel> models_;
+    std::vector<char> live_;
+    std::vector<int> free_slots_;
+    ClusterModel* d_models_ = nullptr;
+    int d_models_cap_ = 0;
+    bool dirty_ = true;
+    PointsSoA pts_;
+    int* d_ids_ = nullptr; int cap_ids_ = 0;
+    int* d_jobs_ = nullptr; int cap_jobs_ = 0;   // train job table (4 ints per job)
+    int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
+    hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+// kernels (ongpis_train.hip / ongpis_test.hip)
+void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
+                          const float* d_pts, int pts_cap, hipStream_t s);
+void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
+void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
+
+struct EvalArgs {
+    const ClusterModel* models;
+    const float4* xq;        // [nq] query points (x, y, z|0, 0)
+    const int* tile_model;   // [ntiles]
+    const int* tile_off;     // [ntiles] first job of the tile in job_q / job_out
+    const int* tile_cnt;     // [ntiles] 1..8
+    const int* job_q;        // query index per job (sorted by model)
+    const int* job_out;      // output record per job
+    float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
+    int use_table;           // exp table in LDS (else recompute per entry)
+};
+// wclass = ongpis_eval_class(nb): 0 -> 1 wave (nb <= 8), 1 -> 4 waves (<= 32), 2 -> 8 waves (<= 64),
+// 3 -> 8 waves x 12 tiles (<= 96); -1 -> cluster too large for this build (K > 3072)
+int ongpis_eval_class(int nb);
+int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args, hipStream_t s);
+
+}  // namespace gpis

@@ -1,0 +1,223 @@
+// Host side of the device OnGPIS model store: pooled per-cluster allocations,
+// the map-point mirror, batched train launches (K6 + K3) and a job-level predict
+// entry (K4) used by the kernel-level C-ABI and the parity tests.
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include "ongpis.h"
+
+namespace gpis {
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {}
+
+OnGPISStore::~OnGPISStore() {
+    clear();
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_ej_);
+    if (ev0_) (void)hipEventDestroy(ev0_);
+    if (ev1_) (void)hipEventDestroy(ev1_);
+    pool_destroy(pool_);
+}
+
+void OnGPISStore::clear() {
+    for (size_t i = 0; i < models_.size(); ++i)
+        if (live_[i] && models_[i].base) pool_free(pool_, models_[i].base);
+    models_.clear(); live_.clear(); free_slots_.clear();
+    dirty_ = true;
+}
+
+int OnGPISStore::new_slot() {
+    int s;
+    if (!free_slots_.empty()) { s = free_slots_.back(); free_slots_.pop_back(); }
+    else { s = (int)models_.size(); models_.emplace_back(); live_.push_back(0); }
+    std::memset(&models_[s], 0, sizeof(ClusterModel));
+    live_[s] = 1;
+    dirty_ = true;
+    return s;
+}
+
+void OnGPISStore::release_slot(int s) {
+    if (s < 0 || s >= (int)models_.size() || !live_[s]) return;
+    if (models_[s].base) pool_free(pool_, models_[s].base);
+    std::memset(&models_[s], 0, sizeof(ClusterModel));
+    live_[s] = 0;
+    free_slots_.push_back(s);
+    dirty_ = true;
+}
+
+size_t OnGPISStore::device_bytes() const { return pool_bytes(pool_); }
+
+int OnGPISStore::alloc_model(int slot, int N, int ng) {
+    ClusterModel& m = models_[slot];
+    int K = N + dim_ * ng;
+    int ld = (int)align_up((size_t)K + 1, 32);
+    size_t oL = 0, szL = sizeof(float) * (size_t)ld * ld;
+    size_t oA = align_up(oL + szL, 256), szA = sizeof(float) * ld;
+    size_t oX = align_up(oA + szA, 256), szX = sizeof(float) * 4 * (size_t)N;
+    size_t oR = align_up(oX + szX, 256), szR = sizeof(int) * ld;
+    size_t oY = align_up(oR + szR, 256), szY = sizeof(float) * ld;
+    size_t oS = align_up(oY + szY, 256), szS = sizeof(float) * 2 * (size_t)N;
+    size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
+    size_t total = align_up(oG + szG, 256);
+    if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
+    char* base = (char*)pool_alloc(pool_, total);
+    if (!base) return GPIS_ERR_HIP;
+    m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
+    m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
+    m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
+    m.base = base;
+    dirty_ = true;
+    return GPIS_OK;
+}
+
+int OnGPISStore::sync_models(hipStream_t s) {
+    if (!dirty_) return GPIS_OK;
+    int n = (int)models_.size();
+    if (n > d_models_cap_) {
+        (void)hipFree(d_models_); d_models_ = nullptr;
+        int cap = n + n / 2 + 64;
+        GPIS_HIP(hipMalloc(&d_models_, sizeof(ClusterModel) * (size_t)cap));
+        d_models_cap_ = cap;
+    }
+    if (n > 0) {
+        GPIS_HIP(hipMemcpyAsync(d_models_, models_.data(), sizeof(ClusterModel) * (size_t)n, hipMemcpyHostToDevice, s));
+        GPIS_HIP(hipStreamSynchronize(s));
+    }
+    dirty_ = false;
+    return GPIS_OK;
+}
+
+int OnGPISStore::upload_points(const float* soa9, int n, hipStream_t s) {
+    if (n > pts_.cap) {
+        (void)hipFree(pts_.d); pts_.d = nullptr;
+        int cap = n + n / 2 + 4096;
+        GPIS_HIP(hipMalloc(&pts_.d, sizeof(float) * 9 * (size_t)cap));
+        pts_.cap = cap;
+    }
+    pts_.n = n;
+    for (int r = 0; r < 9 && n > 0; ++r)
+        GPIS_HIP(hipMemcpyAsync(pts_.d + (size_t)r * pts_.cap, soa9 + (size_t)r * n, sizeof(float) * (size_t)n,
+                                hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    return GPIS_OK;
+}
+
+int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s) {
+    int nj = (int)jobs.size();
+    if (nj == 0) return GPIS_OK;
+    std::vector<int> tab((size_t)4 * nj);
+    for (int j = 0; j < nj; ++j) {
+        const TrainJob& tj = jobs[j];
+        if (tj.model < 0 || tj.model >= (int)models_.size() || !live_[tj.model] || tj.n <= 0) return GPIS_ERR_ARG;
+        int K = tj.n + dim_ * tj.ng;
+        if (ongpis_eval_class((K + 31) / 32) < 0) {
+            fprintf(stderr, "[gpismap_amd] cluster with K=%d exceeds the supported size (3072)\n", K);
+            return GPIS_ERR_LIMIT;
+        }
+        int rc = alloc_model(tj.model, tj.n, tj.ng);
+        if (rc) return rc;
+        tab[4 * j] = tj.model; tab[4 * j + 1] = tj.off; tab[4 * j + 2] = tj.n; tab[4 * j + 3] = tj.ng;
+    }
+    int rc = sync_models(s);
+    if (rc) return rc;
+    if ((int)ids.size() > cap_ids_) {
+        (void)hipFree(d_ids_); d_ids_ = nullptr;
+        int cap = (int)ids.size() * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_ids_, sizeof(int) * (size_t)cap));
+        cap_ids_ = cap;
+    }
+    if (4 * nj > cap_jobs_) {
+        (void)hipFree(d_jobs_); d_jobs_ = nullptr;
+        int cap = 4 * nj * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_jobs_, sizeof(int) * (size_t)cap));
+        cap_jobs_ = cap;
+    }
+    GPIS_HIP(hipMemcpyAsync(d_ids_, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
+    if (profile) {
+        if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
+        GPIS_HIP(hipEventRecord(ev0_, s));
+    }
+    ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
+    ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
+    ongpis_launch_chol(d_models_, d_jobs_, nj, s);
+    GPIS_HIP(hipGetLastError());
+    if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
+    return GPIS_OK;
+}
+
+// Job-level predict with host job arrays: sort by model, cut into tiles of 8, launch per
+// size class.  (The map-level test path bins on the device instead, see map_query.hip.)
+int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
+                           hipStream_t s) {
+    if (njobs <= 0) return GPIS_OK;
+    int rc = sync_models(s);
+    if (rc) return rc;
+    std::vector<int> order(njobs);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_job_model[a] < h_job_model[b]; });
+    std::vector<int> jq(njobs), jo(njobs);
+    std::vector<int> tmodel[4], toff[4], tcnt[4];
+    int maxN[4] = {0, 0, 0, 0};
+    for (int i = 0; i < njobs;) {
+        int mslot = h_job_model[order[i]];
+        const ClusterModel* m = model(mslot);
+        if (!m || !m->base) return GPIS_ERR_ARG;
+        int cls = ongpis_eval_class(m->nb);
+        if (cls < 0) return GPIS_ERR_LIMIT;
+        int e = i;
+        while (e < njobs && h_job_model[order[e]] == mslot) ++e;
+        for (int t = i; t < e; t += 8) {
+            tmodel[cls].push_back(mslot); toff[cls].push_back(t); tcnt[cls].push_back(std::min(8, e - t));
+        }
+        maxN[cls] = std::max(maxN[cls], m->N);
+        for (int t = i; t < e; ++t) { jq[t] = h_job_q[order[t]]; jo[t] = order[t]; }
+        i = e;
+    }
+    size_t ntl = 0;
+    for (int c = 0; c < 4; ++c) ntl += tmodel[c].size();
+    size_t need = 2 * (size_t)njobs + 3 * ntl;
+    if ((int)need > cap_ej_) {
+        (void)hipFree(d_ej_); d_ej_ = nullptr;
+        int cap = (int)need * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_ej_, sizeof(int) * (size_t)cap));
+        cap_ej_ = cap;
+    }
+    int* d_jq = d_ej_;
+    int* d_jo = d_ej_ + njobs;
+    int* d_t = d_ej_ + 2 * njobs;
+    GPIS_HIP(hipMemcpyAsync(d_jq, jq.data(), sizeof(int) * njobs, hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_jo, jo.data(), sizeof(int) * njobs, hipMemcpyHostToDevice, s));
+    std::vector<int> tl;
+    size_t base[4];
+    for (int c = 0; c < 4; ++c) {
+        base[c] = tl.size();
+        tl.insert(tl.end(), tmodel[c].begin(), tmodel[c].end());
+        tl.insert(tl.end(), toff[c].begin(), toff[c].end());
+        tl.insert(tl.end(), tcnt[c].begin(), tcnt[c].end());
+    }
+    if (!tl.empty()) GPIS_HIP(hipMemcpyAsync(d_t, tl.data(), sizeof(int) * tl.size(), hipMemcpyHostToDevice, s));
+    if (profile) {
+        if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
+        GPIS_HIP(hipEventRecord(ev0_, s));
+    }
+    for (int c = 0; c < 4; ++c) {
+        int nt = (int)tmodel[c].size();
+        if (!nt) continue;
+        EvalArgs a;
+        a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
+        a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = 1;
+        rc = ongpis_eval_launch(c, nt, maxN[c], a, s);
+        if (rc) return rc;
+    }
+    if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    if (profile) GPIS_HIP(hipEventElapsedTime(&last_eval_ms, ev0_, ev1_));
+    return GPIS_OK;
+}
+
+}  // namespace gpis

@@ -1,0 +1,84 @@
+/* gpismap_amd -- MI355X-native drop-in for the reference's 3-D map class.
+ *
+ * Mirrors the public surface of reference cpp/include/GPisMap3.h:
+ *   camParam        :29-46   (same members, same defaults)
+ *   GPisMap3Param   :48-81   (same members, same defaults)
+ *   class GPisMap3  :83-140  (same public methods and argument meaning)
+ * The GP regression of update()/test() runs as hand-written HIP kernels on the
+ * GPU (gfx950); the spatial index and the per-point heuristics stay on the host.
+ * No exceptions cross this boundary; like the reference, update() returns
+ * silently on bad input and test() returns false.
+ */
+#ifndef GPISMAP_AMD_GPISMAP3_H_
+#define GPISMAP_AMD_GPISMAP3_H_
+
+#include <vector>
+
+typedef struct camParam_ {
+    float fx;
+    float fy;
+    float cx;
+    float cy;
+    int width;
+    int height;
+
+    camParam_() {
+        width = 640;
+        height = 480;
+        fx = 568.0;
+        fy = 568.0;
+        cx = 310;
+        cy = 224;
+    }
+    camParam_(float fx_, float fy_, float cx_, float cy_, float w_, float h_)
+        : fx(fx_), fy(fy_), cx(cx_), cy(cy_), width(w_), height(h_) {}
+} camParam;
+
+typedef struct GPisMap3Param_ {
+    float delx;          // numerical step delta (surface normal sampling)
+    float fbias;         // constant map bias (mean of the GP)
+    float obs_var_thre;  // ObsGP variance above which a prediction is not trusted
+    int obs_skip;        // use every skip-th pixel
+    float min_position_noise;
+    float min_grad_noise;
+    float map_scale_param;
+    float map_noise_param;
+
+    GPisMap3Param_() {
+        delx = 1e-3;
+        fbias = 0.2;
+        obs_skip = 2;
+        obs_var_thre = 0.04;
+        min_position_noise = 1e-3;
+        min_grad_noise = 1e-2;
+        map_scale_param = 0.04;
+        map_noise_param = 5e-3;
+    }
+} GPisMap3Param;
+
+class GPisMap3 {
+public:
+    GPisMap3();
+    GPisMap3(GPisMap3Param par);
+    GPisMap3(GPisMap3Param par, camParam c);
+    ~GPisMap3();
+    void reset();
+
+    void getAllPoints(std::vector<float>& pos);
+    void update(float* dataz, int N, std::vector<float>& pose);
+    bool test(float* x, int dim, int leng, float* res);
+    void resetCam(camParam c);
+
+    /* Extensions (not in the reference): device-resident queries and introspection. */
+    bool testDevice(const float* d_x, int leng, float* d_res, void* hip_stream);
+    void getAllNodes(std::vector<float>& out9);  /* pos3 grad3 val sigx sigg, tree order */
+    struct Impl;
+    Impl* impl() { return p_; }
+
+private:
+    GPisMap3(const GPisMap3&);
+    GPisMap3& operator=(const GPisMap3&);
+    Impl* p_;
+};
+
+#endif

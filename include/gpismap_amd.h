@@ -1,0 +1,92 @@
+/* gpismap_amd -- C-ABI of the MI355X-native GPisMap hot path.
+ *
+ * Plain pointers and sizes only; every function returns an int status
+ * (0 = GPIS_OK, negative = error) unless stated otherwise and never throws.
+ * Host pointers unless a parameter is named d_* (device pointer).
+ *
+ * Map level: what a binding of the reference's mex gateways would call.
+ *   reference mex/mexGPisMap3.cpp:  'update' :49-78, 'test' :79-110,
+ *   'setCamera' :111-144, 'getAllPoints' :145-157, 'reset' :158-166
+ *   -> class GPisMap3  reference cpp/include/GPisMap3.h:117-127
+ *   reference mex/mexGPisMap.cpp:   'update' :40-85, 'test' :86-122, 'reset' :123-131
+ *   -> class GPisMap   reference cpp/include/GPisMap.h:97-106
+ * Kernel level: the batched GP primitives.
+ */
+#ifndef GPISMAP_AMD_H_
+#define GPISMAP_AMD_H_
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPIS_OK 0
+#define GPIS_ERR_ARG (-1)
+#define GPIS_ERR_HIP (-2)
+#define GPIS_ERR_STATE (-3)
+#define GPIS_ERR_LIMIT (-4)
+
+typedef struct gpis_cam {  /* reference camParam, GPisMap3.h:29-46 */
+    float fx, fy, cx, cy;
+    int width, height;
+} gpis_cam;
+
+/* number of HIP devices visible (0 when no GPU: every compute entry then fails loudly) */
+int gpis_device_count(void);
+const char* gpis_version(void);
+
+/* ---- 3-D map (GPisMap3) -------------------------------------------------- */
+void* gpis3_create(const gpis_cam* cam /* NULL = reference defaults */);
+void  gpis3_destroy(void* map);
+int   gpis3_reset(void* map);                                   /* GPisMap3::reset    GPisMap3.cpp:99  */
+int   gpis3_set_camera(void* map, const gpis_cam* cam);         /* GPisMap3::resetCam GPisMap3.cpp:117 */
+/* depth: width*height floats, column-major (index = col*height + row), metres;
+ * pose12 = [t(3), R column-major(9)].                          GPisMap3::update GPisMap3.cpp:218 */
+int   gpis3_update(void* map, const float* depth, int n, const float* pose12);
+/* x: n*3 interleaved; res: n*8 [f gx gy gz vf vgx vgy vgz], pre-filled by the caller; only the
+ * entries the reference writes are touched.  Returns GPIS_ERR_ARG where the reference returns
+ * false.                                                       GPisMap3::test GPisMap3.cpp:904 */
+int   gpis3_test(void* map, const float* x, int dim, int n, float* res);
+int   gpis3_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
+int   gpis3_num_points(void* map);
+int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
+int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
+/* out[0..]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations,
+ * clusters in table, GP evaluations of last test, ms in K4 of last test (profiling on), device bytes */
+int   gpis3_stats(void* map, double* out, int n);
+int   gpis3_set_profile(void* map, int on);
+
+/* ---- kernel level: observation GP (K1, K2) -------------------------------- */
+void* gpis_obsgp_create(void);
+void  gpis_obsgp_destroy(void* g);
+/* ObsGP2D::train ObsGP.cpp:331: vu = ni*nj interleaved (v,u), f = ni*nj (valid iff > 0) */
+int   gpis_obsgp_train2d(void* g, const float* vu, const float* f, int ni, int nj);
+/* ObsGP1D::train ObsGP.cpp:85 */
+int   gpis_obsgp_train1d(void* g, const float* theta, const float* f, int n);
+/* batched single-point queries (ObsGP2D::test ObsGP.cpp:410 / ObsGP1D::test :145);
+ * q: nq*2 (2-D) or nq (1-D); val is pre-filled by the caller and left untouched where no
+ * group answers (var = 1e6 there) */
+int   gpis_obsgp_query(void* g, const float* q, int nq, float* val, float* var);
+int   gpis_obsgp_num_groups(void* g);
+int   gpis_obsgp_get_group(void* g, int group, int* n, float* x128, float* alpha64, float* L4096);
+
+/* ---- kernel level: OnGPIS batches (K6, K3, K4) ----------------------------- */
+void* gpis_ongpis_create(int dim, float scale);
+void  gpis_ongpis_destroy(void* s);
+/* points: 9 SoA rows of length npts (px py pz gx gy gz val sigx sigg); clusters given as CSR
+ * (off[ncl+1], ids[]) of point ids in training order.  model_out[ncl] receives the model slots.
+ * OnGPIS::train OnGPIS.cpp:91-149 (2-D :34-89) for every cluster. */
+int   gpis_ongpis_train(void* s, const float* points_soa9, int npts, const int* off, const int* ids, int ncl,
+                        int* model_out);
+/* copy a trained model back: sizes via gpis_ongpis_model_dims (N, ng, K, ld) */
+int   gpis_ongpis_model_dims(void* s, int model, int* dims4);
+int   gpis_ongpis_get_model(void* s, int model, float* L_ldxld, float* alpha_K, int* gidx_N);
+/* OnGPIS::testSinglePoint OnGPIS.cpp:177-216 (2-D test2Dpoint :218) for njobs (query, model) pairs.
+ * xq: nq*dim interleaved; out: njobs*8 = mean(4) var(4) (2-D uses 3+3, slots 3 and 7 unused) */
+int   gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs,
+                       float* out8);
+int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -97,6 +97,16 @@ public:
         return true;
     }
 
+    // per-query ambiguity flags (bit0 distance tie, bit1 variance near the 0.5 gate, bit2 near-equal
+    // candidate variances); the outputs themselves are discarded
+    void testFlags(const float* x, int leng, int* flags) {
+        if (!t) return;
+        parallel_for(leng, nthreads, [&](int a, int b) {
+            float r[8];
+            for (int i = a; i < b; ++i) { for (float& v : r) v = 0.f; flags[i] = 0; test_one(x + 3 * (size_t)i, r, &flags[i]); }
+        });
+    }
+
     void getAllPoints(std::vector<float>& pos) {  // :951-972
         pos.clear();
         if (!t) return;
@@ -492,7 +502,7 @@ private:
     }
 
     // One query, GPisMap3.cpp:794-902.  Returns the number of GP evaluations.
-    int test_one(const float* xt, float* res) {
+    int test_one(const float* xt, float* res, int* flag = nullptr) {
         const float var_thre = 0.5f;
         int ev = 0;
         std::vector<T3*> quads;
@@ -506,8 +516,21 @@ private:
             std::vector<int> idx(sqdst.size());
             for (size_t i = 0; i < idx.size(); ++i) idx[i] = (int)i;
             std::sort(idx.begin(), idx.end(), [&](int a, int b) { return sqdst[a] < sqdst[b]; });
+            if (flag) {  // order-ambiguous: an exact distance tie among the (up to) four nearest cells
+                size_t lim = std::min<size_t>(idx.size(), 4);
+                for (size_t i = 1; i < lim; ++i) if (sqdst[idx[i]] == sqdst[idx[i - 1]]) *flag |= 1;
+                // bit3: std::sort (unstable beyond 16 elements) and a stable sort disagree on the three
+                // nearest cells -- the only queries whose result depends on the sort implementation
+                std::vector<int> ids(sqdst.size());
+                for (size_t i = 0; i < ids.size(); ++i) ids[i] = (int)i;
+                std::stable_sort(ids.begin(), ids.end(), [&](int a, int b) { return sqdst[a] < sqdst[b]; });
+                size_t l3 = std::min<size_t>(idx.size(), 3);
+                for (size_t i = 0; i < l3; ++i) if (ids[i] != idx[i]) *flag |= 8;
+                if (idx.size() > 16) *flag |= 16;
+            }
             auto gp = quads[idx[0]]->gp;
             if (gp) { gp->test1(xt, res, res + 4); ++ev; }
+            if (flag && std::fabs(res[4] - var_thre) < 1e-3f) *flag |= 2;  // branch-ambiguous
             if (res[4] > var_thre) {
                 float f2[8], grad2[8 * 3], var2[8 * 4];
                 var2[0] = res[4];
@@ -526,6 +549,10 @@ private:
                 for (int i = 0; i < numc; ++i) id2[i] = i;
                 std::sort(id2.begin(), id2.end(), [&](int a, int b) { return var2[a * 4] < var2[b * 4]; });
                 int b0 = id2[0];
+                if (flag) {
+                    if (std::fabs(var2[b0 * 4] - var_thre) < 1e-3f) *flag |= 2;
+                    for (int i = 1; i < numc; ++i) if (std::fabs(var2[id2[i] * 4] - var2[id2[i - 1] * 4]) < 1e-4f) *flag |= 4;
+                }
                 if (var2[b0 * 4] < var_thre) {
                     res[0] = f2[b0];
                     for (int d = 0; d < 3; ++d) res[1 + d] = grad2[b0 * 3 + d];

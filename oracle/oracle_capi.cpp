@@ -33,6 +33,28 @@ void orc3_update(void* h, const float* depth, int n, const float* pose12) {
 int orc3_test(void* h, const float* x, int dim, int n, float* res) {
     return ((GPisMap3*)h)->test(x, dim, n, res) ? 1 : 0;
 }
+void orc3_test_flags(void* h, const float* x, int n, int* flags) { ((GPisMap3*)h)->testFlags(x, n, flags); }
+// observation grid of the last frame (for component-level K1/K2 parity)
+void orc3_obs_dims(void* h, int* ni, int* nj) {
+    auto* m = (GPisMap3*)h;
+    *ni = m->cam.height / m->setting.obs_skip; *nj = m->cam.width / m->setting.obs_skip;
+}
+void orc3_get_obs(void* h, float* vu, float* zinv) {
+    auto* m = (GPisMap3*)h;
+    std::memcpy(vu, m->vu_grid.data(), m->vu_grid.size() * sizeof(float));
+    std::memcpy(zinv, m->obs_zinv.data(), m->obs_zinv.size() * sizeof(float));
+}
+int orc3_obsgp_num_tiles(void* h) { auto* m = (GPisMap3*)h; return m->gpo ? (int)m->gpo->gps.size() : 0; }
+// returns n (0 = untrained); L is n x n column-major
+int orc3_obsgp_tile(void* h, int tile, float* x, float* alpha, float* L) {
+    auto* m = (GPisMap3*)h;
+    if (!m->gpo || tile < 0 || tile >= (int)m->gpo->gps.size() || !m->gpo->gps[tile]) return 0;
+    const GPou& g = *m->gpo->gps[tile];
+    if (x) std::memcpy(x, g.x.data(), g.x.size() * sizeof(float));
+    if (alpha) std::memcpy(alpha, g.alpha.data(), g.alpha.size() * sizeof(float));
+    if (L) std::memcpy(L, g.L.data(), g.L.size() * sizeof(float));
+    return g.n;
+}
 int orc3_num_points(void* h) {
     std::vector<float> p; ((GPisMap3*)h)->getAllPoints(p); return (int)(p.size() / 3);
 }

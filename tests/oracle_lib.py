@@ -42,6 +42,11 @@ def lib():
         L.orc3_num_clusters.argtypes = [C.c_void_p]
         L.orc3_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         L.orc3_obsgp_query.argtypes = [C.c_void_p, fp, C.c_int, fp, fp]
+        L.orc3_test_flags.argtypes = [C.c_void_p, fp, C.c_int, ip]
+        L.orc3_obs_dims.argtypes = [C.c_void_p, ip, ip]
+        L.orc3_get_obs.argtypes = [C.c_void_p, fp, fp]
+        L.orc3_obsgp_num_tiles.argtypes = [C.c_void_p]
+        L.orc3_obsgp_tile.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
         L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
         L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.orc_bwd_subst.argtypes = [fp, C.c_int, C.c_int, fp]
@@ -53,6 +58,33 @@ def lib():
         L.orc_ongpis_predict.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, fp]
         _LIB = L
     return _LIB
+
+
+def ongpis_train(dim, scale, pos, grad, val, sx, sg):
+    """Oracle OnGPIS::train: returns dict(K, L[r,c], alpha, gidx)."""
+    L_ = lib()
+    pos = np.ascontiguousarray(pos, dtype=np.float32); grad = np.ascontiguousarray(grad, dtype=np.float32)
+    val = np.ascontiguousarray(val, dtype=np.float32); sx = np.ascontiguousarray(sx, dtype=np.float32)
+    sg = np.ascontiguousarray(sg, dtype=np.float32)
+    n = val.size
+    gidx = np.zeros(n, dtype=np.int32)
+    K = L_.orc_ongpis_train(dim, C.c_float(scale), _p(pos), _p(grad), _p(val), _p(sx), _p(sg), n, None, None, _p(gidx, C.c_int))
+    Lm = np.zeros(K * K, dtype=np.float32)
+    alpha = np.zeros(K, dtype=np.float32)
+    L_.orc_ongpis_train(dim, C.c_float(scale), _p(pos), _p(grad), _p(val), _p(sx), _p(sg), n, _p(Lm), _p(alpha), _p(gidx, C.c_int))
+    return dict(K=K, L=Lm.reshape(K, K).T.copy(), alpha=alpha, gidx=gidx)
+
+
+def ongpis_predict(dim, scale, pos, grad, val, sx, sg, xq):
+    """Oracle train + testSinglePoint for each query: returns [nq, 2(1+dim)] (mean, var)."""
+    L_ = lib()
+    pos = np.ascontiguousarray(pos, dtype=np.float32); grad = np.ascontiguousarray(grad, dtype=np.float32)
+    val = np.ascontiguousarray(val, dtype=np.float32); sx = np.ascontiguousarray(sx, dtype=np.float32)
+    sg = np.ascontiguousarray(sg, dtype=np.float32); xq = np.ascontiguousarray(xq, dtype=np.float32)
+    nq = xq.shape[0]
+    out = np.zeros((nq, 2 * (1 + dim)), dtype=np.float32)
+    L_.orc_ongpis_predict(dim, C.c_float(scale), _p(pos), _p(grad), _p(val), _p(sx), _p(sg), val.size, _p(xq), nq, _p(out))
+    return out
 
 
 class OracleMap3:
@@ -85,6 +117,30 @@ class OracleMap3:
         res = np.zeros((x.shape[0], 8), dtype=np.float32)
         ok = self.L.orc3_test(self.h, _p(x), 3, x.shape[0], _p(res))
         return res if ok else None
+
+    def test_flags(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        fl = np.zeros(x.shape[0], dtype=np.int32)
+        self.L.orc3_test_flags(self.h, _p(x), x.shape[0], _p(fl, C.c_int))
+        return fl
+
+    def obs(self):
+        ni, nj = C.c_int(0), C.c_int(0)
+        self.L.orc3_obs_dims(self.h, C.byref(ni), C.byref(nj))
+        vu = np.zeros(2 * ni.value * nj.value, dtype=np.float32)
+        zinv = np.zeros(ni.value * nj.value, dtype=np.float32)
+        self.L.orc3_get_obs(self.h, _p(vu), _p(zinv))
+        return vu, zinv, ni.value, nj.value
+
+    def obsgp_tile(self, t):
+        x = np.zeros((64, 2), dtype=np.float32)
+        alpha = np.zeros(64, dtype=np.float32)
+        Lm = np.zeros(64 * 64, dtype=np.float32)
+        n = self.L.orc3_obsgp_tile(self.h, t, _p(x), _p(alpha), _p(Lm))
+        return n, x[:n], alpha[:n], Lm[:n * n].reshape(n, n).T.copy()  # L[r, c]
+
+    def obsgp_num_tiles(self):
+        return self.L.orc3_obsgp_num_tiles(self.h)
 
     def num_points(self):
         return self.L.orc3_num_points(self.h)

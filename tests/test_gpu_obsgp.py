@@ -1,0 +1,92 @@
+"""K1/K2 parity: device ObsGP vs the CPU oracle on data/3D frames and a 1-D laser scan.
+Called through the C-ABI (gpismap_amd.ObsGP -> gpis_obsgp_*)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_after(nframes):
+    frames = replay.load_bigbird()
+    m = oracle_lib.OracleMap3(frames[0]["cam"])
+    for i in range(nframes):
+        if i:
+            m.set_camera(frames[i]["cam"])
+        m.update(frames[i]["depth"], frames[i]["pose"])
+    return m
+
+
+@pytest.mark.parametrize("nframes", [1, 3])
+def test_obsgp2d_train_and_query_match_oracle(nframes):
+    import gpismap_amd
+    om = _oracle_after(nframes)
+    vu, zinv, ni, nj = om.obs()
+    g = gpismap_amd.ObsGP()
+    g.train2d(vu, zinv, ni, nj)
+    assert g.num_groups() == om.obsgp_num_tiles() == 48 * 64
+    ntr = 0
+    worst_L = worst_a = 0.0
+    exact = total = 0
+    for t in range(g.num_groups()):
+        n, x, alpha, L = g.group(t)
+        on, ox, oalpha, oL = om.obsgp_tile(t)
+        assert n == on, (t, n, on)
+        if n == 0:
+            continue
+        ntr += 1
+        np.testing.assert_array_equal(x[:n], ox)
+        Lg = np.tril(L[:n, :n])
+        worst_L = max(worst_L, float(np.abs(Lg - np.tril(oL)).max()))
+        worst_a = max(worst_a, float(np.abs(alpha[:n] - oalpha).max() / (np.abs(oalpha).max() + 1e-30)))
+        exact += int((Lg == np.tril(oL)).sum()) + int((alpha[:n] == oalpha).sum())
+        total += Lg.size + n
+    print("tiles trained %d, L max abs diff %.3e, alpha max rel diff %.3e, bit-identical %.6f" % (ntr, worst_L, worst_a, exact / total))
+    assert ntr > 50
+    # fixed chain order => identical up to a rare 1-ulp difference of exp() between glibc and the device
+    assert worst_L < 1e-6
+    assert worst_a < 1e-4
+
+    # queries: every valid pixel centre plus jittered copies (some fall outside / on untrained tiles)
+    rng = np.random.default_rng(7)
+    valid = np.nonzero(zinv > 0)[0]
+    q = np.stack([vu[2 * valid], vu[2 * valid + 1]], axis=1)
+    q = np.concatenate([q, q + rng.normal(0, 2e-3, q.shape).astype(np.float32),
+                        rng.uniform(-0.6, 0.6, (2000, 2)).astype(np.float32)]).astype(np.float32)
+    val, var = g.query(q)
+    oval, ovar = om.obsgp_query(q)
+    hit = ovar < 1e5
+    assert np.array_equal(hit, var < 1e5)
+    assert hit.sum() > 1000
+    dv = np.abs(val[hit] - oval[hit]).max()
+    dr = np.abs(var[hit] - ovar[hit]).max()
+    same = float(np.mean((val[hit] == oval[hit]) & (var[hit] == ovar[hit])))
+    print("queries %d answered %d, max |dval| %.3e max |dvar| %.3e bit-identical %.6f" % (q.shape[0], hit.sum(), dv, dr, same))
+    assert dv < 1e-5 and dr < 1e-5
+    assert np.all(val[~hit] == 0) and np.all(var[~hit] == np.float32(1e6))
+
+
+def test_obsgp1d_matches_oracle():
+    import gpismap_amd
+    z = np.load(replay.GOLDEN + "/gazebo2d_seq.npz")
+    theta = z["thetas"].astype(np.float32)
+    f = (1.0 / np.sqrt(z["ranges"][0].astype(np.float32))).astype(np.float32)
+    g = gpismap_amd.ObsGP()
+    g.train1d(theta, f)
+    assert g.num_groups() == 14
+    sizes = [g.group(i)[0] for i in range(14)]
+    assert sizes == [26] * 12 + [22, 15]
+    L_ = oracle_lib.lib()
+    import ctypes as C
+    # oracle per group
+    starts = [20 * i for i in range(12)] + [240, 255]
+    for gi, (a, n) in enumerate(zip(starts, sizes)):
+        x = np.ascontiguousarray(theta[a:a + n]); ff = np.ascontiguousarray(f[a:a + n])
+        oL = np.zeros(n * n, dtype=np.float32); oa = np.zeros(n, dtype=np.float32)
+        L_.orc_gpou_train(oracle_lib._p(x), oracle_lib._p(ff), 1, n, oracle_lib._p(oL), oracle_lib._p(oa))
+        _, gx, ga, gL = g.group(gi)
+        np.testing.assert_array_equal(gx[:n, 0], x)
+        assert np.abs(np.tril(gL[:n, :n]) - np.tril(oL.reshape(n, n).T)).max() < 1e-6
+        assert np.abs(ga[:n] - oa).max() <= 1e-4 * np.abs(oa).max()

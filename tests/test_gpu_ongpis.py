@@ -1,0 +1,112 @@
+"""K6/K3/K4 parity: batched OnGPIS train + predict vs the CPU oracle on synthetic clusters of
+several sizes (all K4 workgroup classes) in 3-D and 2-D.  Through the C-ABI (gpis_ongpis_*)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+
+pytestmark = pytest.mark.gpu
+
+
+def make_cluster(rng, dim, n, scale, frac_nograd=0.2):
+    """Points on a wavy surface patch with unit normals and the reference's noise ranges."""
+    ext = scale * 2.0
+    pos = rng.uniform(-ext, ext, (n, dim)).astype(np.float32)
+    if dim == 3:
+        pos[:, 2] = (0.2 * ext * np.sin(3 * pos[:, 0] / ext) * np.cos(2 * pos[:, 1] / ext)).astype(np.float32)
+        nrm = np.stack([-0.3 * np.cos(3 * pos[:, 0] / ext), 0.2 * np.sin(2 * pos[:, 1] / ext), np.ones(n)], axis=1)
+    else:
+        pos[:, 1] = (0.2 * ext * np.sin(3 * pos[:, 0] / ext)).astype(np.float32)
+        nrm = np.stack([-0.3 * np.cos(3 * pos[:, 0] / ext), np.ones(n)], axis=1)
+    nrm = (nrm / np.linalg.norm(nrm, axis=1, keepdims=True)).astype(np.float32)
+    val = np.full(n, -0.2, dtype=np.float32)
+    sx = rng.uniform(1e-3, 5e-3, n).astype(np.float32)
+    sg = rng.uniform(0.01, 0.1, n).astype(np.float32)
+    k = int(frac_nograd * n)
+    sg[:k // 2] = 0.5            # too uncertain -> value-only point
+    nrm[k // 2:k] = 0.0          # no normal -> value-only point
+    return pos, nrm, val, sx, sg
+
+
+def soa9(dim, pos, grad, val, sx, sg):
+    n = val.size
+    P = np.zeros((9, n), dtype=np.float32)
+    P[0:dim] = pos.T
+    P[3:3 + dim] = grad.T
+    P[6], P[7], P[8] = val, sx, sg
+    return P
+
+
+@pytest.mark.parametrize("dim,scale,sizes", [
+    (3, 0.04, [1, 7, 40, 64, 150, 230]),        # K up to ~800: classes 0 and 1
+    (3, 0.04, [420, 700]),                       # K ~1400 / ~2300: classes 2 and 3
+    (2, 1.2, [3, 26, 90, 180]),
+])
+def test_train_and_predict_match_oracle(dim, scale, sizes):
+    import gpismap_amd
+    rng = np.random.default_rng(100 + dim + len(sizes))
+    clusters = [make_cluster(rng, dim, n, scale) for n in sizes]
+    pos = np.concatenate([c[0] for c in clusters]); grad = np.concatenate([c[1] for c in clusters])
+    val = np.concatenate([c[2] for c in clusters]); sx = np.concatenate([c[3] for c in clusters])
+    sg = np.concatenate([c[4] for c in clusters])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    # training order inside a cluster is the id order given: shuffle to exercise the gather
+    ids = np.concatenate([off[i] + rng.permutation(sizes[i]) for i in range(len(sizes))]).astype(np.int32)
+    st = gpismap_amd.OnGPIS(dim, scale)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), off, ids)
+    print("train ms", st.last_ms()[0])
+    jq, jm, xq_all, ref_all = [], [], [], []
+    for ci, n in enumerate(sizes):
+        sel = ids[off[ci]:off[ci + 1]]
+        o = oracle_lib.ongpis_train(dim, scale, pos[sel], grad[sel], val[sel], sx[sel], sg[sel])
+        g = st.model(models[ci])
+        assert (g["N"], g["K"]) == (n, o["K"])
+        np.testing.assert_array_equal(g["gidx"], o["gidx"])
+        K = o["K"]
+        Lg = np.tril(g["L"][:K, :K]); Lo = np.tril(o["L"])
+        dL = float(np.abs(Lg - Lo).max())
+        da = float(np.abs(g["alpha"] - o["alpha"]).max() / (np.abs(o["alpha"]).max() + 1e-30))
+        same = float(np.mean(Lg == Lo))
+        print("cluster N=%d K=%d: L max|d| %.3e (bit-identical %.5f), alpha rel %.3e" % (n, K, dL, same, da))
+        assert dL < 2e-5 * max(1.0, float(np.abs(Lo).max()))
+        assert da < 1e-3
+        # padded square must be a valid triangular factor: identity outside K
+        ld = g["ld"]
+        pad = g["L"][K:ld, :]
+        assert np.array_equal(np.tril(pad[:, K:ld]), np.eye(ld - K, dtype=np.float32))
+        assert np.all(pad[:, :K] == 0)
+        # queries: near the surface, off the surface, far away
+        nq = 37
+        xq = pos[sel][rng.integers(0, n, nq)] + rng.normal(0, 0.3 * scale, (nq, dim)).astype(np.float32)
+        xq[-3:] += 5 * scale
+        base = sum(x.shape[0] for x in xq_all)
+        xq_all.append(xq.astype(np.float32))
+        ref_all.append(oracle_lib.ongpis_predict(dim, scale, pos[sel], grad[sel], val[sel], sx[sel], sg[sel], xq))
+        jq.extend(range(base, base + nq)); jm.extend([models[ci]] * nq)
+    xq = np.concatenate(xq_all); ref = np.concatenate(ref_all)
+    perm = rng.permutation(len(jq))          # unsorted jobs: the store sorts by model
+    out = st.eval(xq, np.array(jq)[perm], np.array(jm)[perm])
+    got = np.zeros_like(out); got[perm] = out
+    nc = 1 + dim
+    mean_g, var_g = got[:, :nc], got[:, 4:4 + nc]
+    mean_o, var_o = ref[:, :nc], ref[:, nc:]
+    tos = 3.0 / (scale * scale)
+    d_f = np.abs(mean_g[:, 0] - mean_o[:, 0]).max()
+    d_g = np.abs(mean_g[:, 1:] - mean_o[:, 1:]).max()
+    d_vf = np.abs(var_g[:, 0] - var_o[:, 0]).max()
+    d_vg = (np.abs(var_g[:, 1:] - var_o[:, 1:]) / tos).max()
+    print("predict: max|df| %.3e max|dgrad| %.3e max|dvar_f| %.3e max rel dvar_g %.3e (eval ms %.3f)" % (d_f, d_g, d_vf, d_vg, st.last_ms()[1]))
+    assert d_f < 2e-5          # SDF value
+    assert d_g < 2e-3          # gradients are O(1/scale)
+    assert d_vf < 1e-4         # abs < 1e-4
+    assert d_vg < 1e-4         # relative to the prior 3/s^2
+
+
+def test_oversize_cluster_is_refused():
+    import gpismap_amd
+    rng = np.random.default_rng(3)
+    n = 900                                    # K = 3600 > 3072
+    pos, nrm, val, sx, sg = make_cluster(rng, 3, n, 0.04, frac_nograd=0.0)
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    with pytest.raises(gpismap_amd.GpisError):
+        st.train(soa9(3, pos, nrm, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
