@@ -92,7 +92,8 @@ class GPisMap3:
     """Mirror of the reference's mexGPisMap3 command set on the HIP path."""
 
     STAT_KEYS = ("obsgp_groups", "obsgp_queries", "clusters_trained", "late_reevals", "clusters",
-                 "last_test_evals", "last_test_k4_ms", "device_bytes")
+                 "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
+                 "last_train_ms", "model_bytes")
 
     def __init__(self, cam6=None):
         self.L = lib()
@@ -156,8 +157,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 8)()
-        _check(self.L.gpis3_stats(self.h, a, 8), "gpis3_stats")
+        a = (C.c_double * 12)()
+        _check(self.L.gpis3_stats(self.h, a, 12), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def set_profile(self, on=True):

@@ -85,6 +85,7 @@ struct GPisMap3::Impl {
 
     // statistics
     long stat_obs_queries = 0, stat_clusters_trained = 0, stat_late = 0;
+    double stat_model_bytes = 0;  // sum over live models of 4 [dN + K + K(K+1)/2] (SURVEY 8d model_bytes)
     float last_update_ms[6] = {0, 0, 0, 0, 0, 0};
 
     Impl(const GPisMap3Param& par, const camParam& c)
@@ -562,6 +563,11 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         for (int d = 0; d < 3; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
         ent[i].model = t.model;
     }
+    stat_model_bytes = 0;
+    for (size_t i = 0; i < cl.size(); ++i) {
+        const ClusterModel* mm = store.model(tree.nodes[cl[i]].model);
+        if (mm && mm->base) stat_model_bytes += 4.0 * (3.0 * mm->N + mm->K + 0.5 * (double)mm->K * (mm->K + 1));
+    }
     int rc = mq.set_clusters(ent, 2.0 * (double)kCleng, stream);
     if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
 }
@@ -648,10 +654,11 @@ void GPisMap3::getAllNodes(std::vector<float>& out) {
 // accessors used by the C-ABI (capi.cpp)
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
-    double v[8] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
-                   (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
-                   (double)m.store.device_bytes()};
-    for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+    double v[12] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+                    (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
+                    (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
+                    (double)m.store.last_train_ms, (double)m.stat_model_bytes};
+    for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

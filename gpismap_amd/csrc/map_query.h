@@ -38,6 +38,7 @@ public:
     int num_clusters() const { return ncl_; }
     // statistics of the last run
     long long last_evals = 0, last_flops = 0, last_touched = 0;
+    int last_launches = 0;      // K4 launches of the last run
     float last_eval_ms = 0.f;   // time inside the K4 launches (hipEvents on the stream)
     int chunk = 1 << 22;
     bool profile = false;

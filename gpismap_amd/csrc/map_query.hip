@@ -135,22 +135,27 @@ __global__ void hist_kernel(const int* __restrict__ jm, int njobs, int* __restri
 __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restrict__ models, int nmodels,
                                                     const int* __restrict__ cnt, int* __restrict__ base,
                                                     int* __restrict__ tbase, int* __restrict__ cursor,
-                                                    int* __restrict__ tot) {
+                                                    int* __restrict__ tot, unsigned long long* __restrict__ flops) {
     __shared__ int sj[1024];
+    __shared__ unsigned long long sf[1024];
     __shared__ int st[4][1024];
     const int tid = threadIdx.x;
     const int chunk = (nmodels + 1023) / 1024;
     const int m0 = tid * chunk, m1 = min(nmodels, m0 + chunk);
     int aj = 0, at[4] = {0, 0, 0, 0};
+    unsigned long long af = 0;
     for (int m = m0; m < m1; ++m) {
         int c = cnt[m];
         if (c > 0) {
             int nb = models[m].nb;
             int cls = nb <= 8 ? 0 : (nb <= 32 ? 1 : (nb <= 64 ? 2 : 3));
             aj += c; at[cls] += (c + 7) / 8;
+            // algorithmic flops of one evaluation: (1+d) K^2 + 2 (1+d) K + 25 N
+            unsigned long long K = models[m].K, N = models[m].N, d1 = 1 + models[m].dim;
+            af += (unsigned long long)c * (d1 * K * K + 2 * d1 * K + 25 * N);
         }
     }
-    sj[tid] = aj;
+    sj[tid] = aj; sf[tid] = af;
     for (int k = 0; k < 4; ++k) st[k][tid] = at[k];
     __syncthreads();
     if (tid == 0) {
@@ -160,6 +165,9 @@ __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restri
             for (int k = 0; k < 4; ++k) { int u = st[k][i]; st[k][i] = rt[k]; rt[k] += u; }
         }
         tot[4] = rj;
+        unsigned long long fs = 0;
+        for (int i = 0; i < 1024; ++i) fs += sf[i];
+        flops[0] = fs;
         int off = 0;
         for (int k = 0; k < 4; ++k) { tot[k] = rt[k]; tot[8 + k] = off; off += rt[k]; }
     }
@@ -359,7 +367,7 @@ int MapQuery::ensure_scratch(int n, int nmodels) {
         GPIS_HIP(hipMalloc(&d_tbase_, sizeof(int) * c));
         cap_models_ = c;
     }
-    if (!d_tot_) GPIS_HIP(hipMalloc(&d_tot_, sizeof(int) * 16));
+    if (!d_tot_) GPIS_HIP(hipMalloc(&d_tot_, sizeof(int) * 32));
     return GPIS_OK;
 }
 
@@ -368,7 +376,7 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     GPIS_HIP(hipMemsetAsync(d_cnt_, 0, sizeof(int) * (size_t)nmodels, s));
     hipLaunchKernelGGL(hist_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, d_cnt_);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, store.d_models(), nmodels, d_cnt_, d_base_, d_tbase_,
-                       d_cursor_, d_tot_);
+                       d_cursor_, d_tot_, reinterpret_cast<unsigned long long*>(d_tot_ + 16));
     hipLaunchKernelGGL(scatter_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, shift, rec_base, d_base_,
                        d_cursor_, d_jq_, d_jo_);
     int* t_model = d_tile_;
@@ -376,10 +384,12 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     int* t_cnt = d_tile_ + 2 * (size_t)tile_cap_;
     hipLaunchKernelGGL(tiles_kernel, dim3(nmodels), dim3(64), 0, s, store.d_models(), nmodels, d_cnt_, d_base_, d_tbase_,
                        d_tot_, t_model, t_off, t_cnt);
-    int tot[16];
-    GPIS_HIP(hipMemcpyAsync(tot, d_tot_, sizeof(int) * 16, hipMemcpyDeviceToHost, s));
+    int tot[20];
+    GPIS_HIP(hipMemcpyAsync(tot, d_tot_, sizeof(int) * 20, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
     last_evals += tot[4];
+    { unsigned long long f; std::memcpy(&f, tot + 16, sizeof(f)); last_flops += (long long)f; }
+    for (int c = 0; c < 4; ++c) if (tot[c] > 0) ++last_launches;
     if (profile) {
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
@@ -432,7 +442,7 @@ int MapQuery::run_chunk(OnGPISStore& store, const float* d_x, int n, float* d_re
 }
 
 int MapQuery::run(OnGPISStore& store, const float* d_x, int n, float* d_res, hipStream_t s) {
-    last_evals = 0; last_eval_ms = 0.f;
+    last_evals = 0; last_eval_ms = 0.f; last_flops = 0; last_launches = 0;
     if (n <= 0) return GPIS_OK;
     int rc = store.sync_models(s);
     if (rc) return rc;

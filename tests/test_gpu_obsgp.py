@@ -9,23 +9,27 @@ import replay
 pytestmark = pytest.mark.gpu
 
 
-def _oracle_after(nframes):
+def _oracle_after(nframes, dev=None):
+    """Replays nframes on the oracle; the device ObsGP (if given) is re-trained on every frame's
+    grid so that it keeps the FIRST frame's tile boundaries like the reference (SURVEY B-15)."""
     frames = replay.load_bigbird()
     m = oracle_lib.OracleMap3(frames[0]["cam"])
     for i in range(nframes):
         if i:
             m.set_camera(frames[i]["cam"])
         m.update(frames[i]["depth"], frames[i]["pose"])
+        if dev is not None:
+            vu, zinv, ni, nj = m.obs()
+            dev.train2d(vu, zinv, ni, nj)
     return m
 
 
 @pytest.mark.parametrize("nframes", [1, 3])
 def test_obsgp2d_train_and_query_match_oracle(nframes):
     import gpismap_amd
-    om = _oracle_after(nframes)
-    vu, zinv, ni, nj = om.obs()
     g = gpismap_amd.ObsGP()
-    g.train2d(vu, zinv, ni, nj)
+    om = _oracle_after(nframes, g)
+    vu, zinv, ni, nj = om.obs()
     assert g.num_groups() == om.obsgp_num_tiles() == 48 * 64
     ntr = 0
     worst_L = worst_a = 0.0
