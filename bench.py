@@ -39,6 +39,7 @@ def main():
     import torch
     import torch.distributed as dist
     import gpismap_amd
+    from gpismap_amd import sharding
     import replay
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -67,21 +68,21 @@ def main():
 
     n_total = args.grid ** 3
     grid = replay.synthetic_grid(args.grid)                    # [n,3] float32, x fastest
-    lo = (n_total * rank) // world
-    hi = (n_total * (rank + 1)) // world
+    lo, hi = sharding.slab_bounds(n_total, world, rank)
     x = torch.from_numpy(grid[lo:hi]).to(dev)                  # resident in HBM before timing
-    res = torch.zeros((hi - lo, 8), dtype=torch.float32, device=dev)
-    gathered = None
+    full = None
     if world > 1 and rank == 0:
-        gathered = [torch.empty(((n_total * (r + 1)) // world - (n_total * r) // world, 8), dtype=torch.float32, device=dev)
-                    for r in range(world)]
+        full = torch.zeros((n_total, 8), dtype=torch.float32, device=dev)   # the assembled map
+        res = full[lo:hi]
+    else:
+        res = torch.zeros((hi - lo, 8), dtype=torch.float32, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
     gm.set_profile(True)                                       # hipEvents around the K4 launches
 
     def step():
         gm.test_device(x.data_ptr(), hi - lo, res.data_ptr(), stream)
         if world > 1:
-            dist.gather(res, gathered, dst=0)
+            sharding.gather_slabs(res, n_total, world, rank, dst=0, out=full)
 
     def barrier():
         if world > 1:

@@ -1,0 +1,133 @@
+"""CPU tests of the product's host side: C-ABI surface, std::sort emulation, replay harness,
+and the multi-rank slab/gather logic over gloo (world_size 2)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import replay
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    import gpismap_amd
+    L = C.CDLL(gpismap_amd.LIB_PATH)        # loads without a GPU
+    hdr = open(os.path.join(ROOT, "include", "gpismap_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(gpis[0-9a-z_]*)\s*\(", hdr))
+    assert len(names) >= 28
+    for n in sorted(names):
+        assert hasattr(L, n), "missing symbol " + n
+    L.gpis_version.restype = C.c_char_p
+    assert b"gfx950" in L.gpis_version()
+
+
+def test_no_cpu_fallback_without_gpu():
+    """Without a HIP device the compute entry points must fail loudly, never fall back."""
+    import gpismap_amd
+    if gpismap_amd.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(gpismap_amd.GpisError):
+        gpismap_amd.GPisMap3()
+    with pytest.raises(gpismap_amd.GpisError):
+        gpismap_amd.ObsGP()
+    with pytest.raises(gpismap_amd.GpisError):
+        gpismap_amd.OnGPIS(3, 0.04)
+
+
+def test_product_does_not_reference_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "gpismap_amd")):
+        for f in fs:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"oracle[/_]|libgpis_oracle|arbiter64", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+def test_stdsort_emulation_matches_libstdcxx(tmp_path):
+    src = tmp_path / "t.cpp"
+    src.write_text(r'''
+#include <algorithm>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "%s/gpismap_amd/csrc/stdsort_emul.h"
+int main() {
+    std::mt19937 rng(5);
+    long bad = 0;
+    for (int trial = 0; trial < 60000; ++trial) {
+        int n = 2 + rng() %% 127;
+        int levels = 1 + rng() %% 6;
+        std::vector<float> key(n);
+        for (auto& k : key) k = (float)(rng() %% levels) * 0.25f;
+        std::vector<int> a(n), b(n);
+        for (int i = 0; i < n; ++i) a[i] = b[i] = i;
+        std::sort(a.begin(), a.end(), [&](int x, int y) { return key[x] < key[y]; });
+        if (!gpis::stdsort_emulate(key.data(), b.data(), n) || a != b) ++bad;
+    }
+    std::printf("%%ld\n", bad);
+    return bad != 0;
+}
+''' % ROOT)
+    exe = tmp_path / "t"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", str(src), "-o", str(exe)])
+    assert subprocess.check_output([str(exe)]).strip() == b"0"
+
+
+def test_replay_harness_shapes():
+    seq = replay.demo3_sequence()
+    assert len(seq) == 40 and seq[0] == (93, 1) and seq[1] == (102, 2)
+    g = replay.demo3_grid()
+    assert g.shape == (21 * 25 * 29, 3)
+    assert np.allclose(g[0], [-0.07, -0.10, 0.0]) and np.allclose(g[1], [-0.07, -0.09, 0.0])   # y fastest
+    fr = replay.load_bigbird()
+    assert len(fr) == 40 and fr[0]["depth"].shape == (307200,)
+    d = replay.synthetic_depth(0)
+    # column-major: index = col*480 + row; centre pixel (310, 224) is exactly 1 m
+    assert d.shape == (307200,) and abs(d[310 * 480 + 224] - 1.0) < 1e-7
+    q = replay.synthetic_grid(4)
+    assert q.shape == (64, 3) and q[1, 0] > q[0, 0] and q[1, 1] == q[0, 1]                      # x fastest
+
+
+def _gloo_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from gpismap_amd import sharding
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1003
+    lo, hi = sharding.slab_bounds(n, world, rank)
+    full = torch.arange(n * 8, dtype=torch.float32).reshape(n, 8)
+    mine = full[lo:hi].clone()                      # stands for this rank's test() output
+    got = sharding.gather_slabs(mine, n, world, rank, dst=0)
+    ok = True
+    if rank == 0:
+        ok = bool(torch.equal(got, full))
+    parts = sharding.shard_clusters([5.0, 1.0, 9.0, 3.0, 3.0, 2.0, 8.0], world)
+    ok = ok and sorted(sum(parts, [])) == list(range(7))
+    out.put((rank, ok, (lo, hi)))
+    dist.destroy_process_group()
+
+
+def test_slab_gather_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(timeout=60)
+    assert all(r[1] for r in res), res
+    assert res[0][2] == (0, 501) and res[1][2] == (501, 1003)
