@@ -23,11 +23,10 @@ def test_chol_and_substitutions_against_float64():
     for n in (1, 5, 33, 120):
         A = rng.normal(size=(n, n))
         K = (A @ A.T + n * np.eye(n)).astype(np.float32)
-        buf = np.asfortranarray(K).T.copy()           # column-major bytes of K
-        flat = np.ascontiguousarray(K.T.reshape(-1))  # element (r, c) at r + c*n
+        ref = np.linalg.cholesky(K.astype(np.float64))
+        flat = K.T.reshape(-1).copy()                 # column-major: element (r, c) at r + c*n
         L_.orc_chol_lower(oracle_lib._p(flat), n, n)
         Lm = np.tril(flat.reshape(n, n).T)
-        ref = np.linalg.cholesky(K.astype(np.float64))
         assert np.abs(Lm - ref).max() < 5e-6 * np.abs(ref).max()
         b = rng.normal(size=n).astype(np.float32)
         x = b.copy()
