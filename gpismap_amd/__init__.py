@@ -55,6 +55,14 @@ def lib():
     L.gpis3_get_nodes.argtypes = [vp, fp, C.c_int]
     L.gpis3_stats.argtypes = [vp, dp, C.c_int]
     L.gpis3_set_profile.argtypes = [vp, C.c_int]
+    L.gpis2_create.restype = vp
+    L.gpis2_destroy.argtypes = [vp]
+    L.gpis2_reset.argtypes = [vp]
+    L.gpis2_update.argtypes = [vp, fp, fp, C.c_int, fp]
+    L.gpis2_test.argtypes = [vp, fp, C.c_int, C.c_int, fp]
+    L.gpis2_test_device.argtypes = [vp, vp, C.c_int, vp, vp]
+    L.gpis2_get_nodes.argtypes = [vp, fp, C.c_int]
+    L.gpis2_stats.argtypes = [vp, dp, C.c_int]
     L.gpis_obsgp_create.restype = vp
     L.gpis_obsgp_destroy.argtypes = [vp]
     L.gpis_obsgp_train2d.argtypes = [vp, fp, fp, C.c_int, C.c_int]
@@ -163,6 +171,58 @@ class GPisMap3:
 
     def set_profile(self, on=True):
         _check(self.L.gpis3_set_profile(self.h, int(on)), "gpis3_set_profile")
+
+
+class GPisMap:
+    """Mirror of the reference's mexGPisMap command set ('update', 'test', 'reset') on the HIP path."""
+
+    def __init__(self):
+        self.L = lib()
+        if self.L.gpis_device_count() < 1:
+            raise GpisError("no HIP device: gpismap_amd has no CPU fallback")
+        self.h = C.c_void_p(self.L.gpis2_create())
+        if not self.h:
+            raise GpisError("gpis2_create failed")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.gpis2_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        _check(self.L.gpis2_reset(self.h), "gpis2_reset")
+
+    def update(self, thetas, ranges, pose6):
+        thetas = np.ascontiguousarray(thetas, dtype=np.float32)
+        ranges = np.ascontiguousarray(ranges, dtype=np.float32)
+        pose6 = np.ascontiguousarray(pose6, dtype=np.float32)
+        if pose6.size != 6 or thetas.size != ranges.size:
+            raise GpisError("bad 2-D update arguments")
+        _check(self.L.gpis2_update(self.h, _p(thetas), _p(ranges), ranges.size, _p(pose6)), "gpis2_update")
+
+    def test(self, x, res=None):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if res is None:
+            res = np.zeros((x.shape[0], 6), dtype=np.float32)
+        rc = self.L.gpis2_test(self.h, _p(x), 2, x.shape[0], _p(res))
+        if rc == -1:
+            return None
+        _check(rc, "gpis2_test")
+        return res
+
+    def nodes(self):
+        n = self.L.gpis2_get_nodes(self.h, None, 0)
+        out = np.zeros((n, 7), dtype=np.float32)
+        if n:
+            self.L.gpis2_get_nodes(self.h, _p(out), n)
+        return out
+
+    def stats(self):
+        a = (C.c_double * 12)()
+        _check(self.L.gpis2_stats(self.h, a, 12), "gpis2_stats")
+        return dict(zip(GPisMap3.STAT_KEYS, list(a)))
 
 
 class ObsGP:

@@ -2,6 +2,7 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include "../../include/GPisMap.h"
 #include "../../include/GPisMap3.h"
 #include "../../include/gpismap_amd.h"
 #include "map_query.h"
@@ -13,6 +14,7 @@ using namespace gpis;
 // accessors implemented in gpismap3.cpp
 void gpis3_impl_stats(GPisMap3* m, double* out, int n);
 void gpis3_impl_profile(GPisMap3* m, int on);
+void gpis2_impl_stats(GPisMap* m, double* out, int n);
 
 extern "C" {
 
@@ -79,6 +81,39 @@ int gpis3_get_nodes(void* m, float* out, int cap) {
 }
 int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis3_impl_stats((GPisMap3*)m, out, n); return GPIS_OK; }
 int gpis3_set_profile(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_profile((GPisMap3*)m, on); return GPIS_OK; }
+
+// ---- 2-D map ----------------------------------------------------------------
+void* gpis2_create(void) { try { return new GPisMap(); } catch (...) { return nullptr; } }
+void gpis2_destroy(void* m) { delete (GPisMap*)m; }
+int gpis2_reset(void* m) { if (!m) return GPIS_ERR_ARG; ((GPisMap*)m)->reset(); return GPIS_OK; }
+int gpis2_update(void* m, const float* thetas, const float* ranges, int n, const float* pose6) {
+    if (!m || !thetas || !ranges || !pose6) return GPIS_ERR_ARG;
+    if (gpis_device_count() < 1) return GPIS_ERR_HIP;
+    try {
+        std::vector<float> pose(pose6, pose6 + 6);
+        ((GPisMap*)m)->update(const_cast<float*>(thetas), const_cast<float*>(ranges), n, pose);
+    } catch (...) { return GPIS_ERR_STATE; }
+    return GPIS_OK;
+}
+int gpis2_test(void* m, const float* x, int dim, int n, float* res) {
+    if (!m) return GPIS_ERR_ARG;
+    if (gpis_device_count() < 1) return GPIS_ERR_HIP;
+    try { return ((GPisMap*)m)->test(const_cast<float*>(x), dim, n, res) ? GPIS_OK : GPIS_ERR_ARG; }
+    catch (...) { return GPIS_ERR_STATE; }
+}
+int gpis2_test_device(void* m, const float* d_x, int n, float* d_res, void* stream) {
+    if (!m) return GPIS_ERR_ARG;
+    try { return ((GPisMap*)m)->testDevice(d_x, n, d_res, stream) ? GPIS_OK : GPIS_ERR_ARG; }
+    catch (...) { return GPIS_ERR_STATE; }
+}
+int gpis2_get_nodes(void* m, float* out, int cap) {
+    if (!m) return GPIS_ERR_ARG;
+    std::vector<float> p; ((GPisMap*)m)->getAllNodes(p);
+    int n = (int)(p.size() / 7);
+    if (out && n <= cap && n > 0) std::memcpy(out, p.data(), p.size() * sizeof(float));
+    return n;
+}
+int gpis2_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis2_impl_stats((GPisMap*)m, out, n); return GPIS_OK; }
 
 // ---- ObsGP --------------------------------------------------------------------
 struct ObsHandle { ObsGPDevice g; hipStream_t s = nullptr; };

@@ -55,6 +55,19 @@ int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 va
 int   gpis3_stats(void* map, double* out, int n);
 int   gpis3_set_profile(void* map, int on);
 
+/* ---- 2-D map (GPisMap) ---------------------------------------------------- */
+void* gpis2_create(void);                                       /* GPisMap() GPisMap.cpp:57 */
+void  gpis2_destroy(void* map);
+int   gpis2_reset(void* map);                                   /* GPisMap::reset GPisMap.cpp:90 */
+/* thetas / ranges: n floats each (radians, metres); pose6 = [tx ty R11 R21 R12 R22].
+ *                                                               GPisMap::update GPisMap.cpp:151 */
+int   gpis2_update(void* map, const float* thetas, const float* ranges, int n, const float* pose6);
+/* x: n*2 interleaved; res: n*6 [f gx gy vf vgx vgy], pre-filled by the caller.  GPisMap::test GPisMap.cpp:765 */
+int   gpis2_test(void* map, const float* x, int dim, int n, float* res);
+int   gpis2_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
+int   gpis2_get_nodes(void* map, float* out7, int cap);         /* pos2 grad2 val sigx sigg, tree order */
+int   gpis2_stats(void* map, double* out, int n);               /* same slots as gpis3_stats */
+
 /* ---- kernel level: observation GP (K1, K2) -------------------------------- */
 void* gpis_obsgp_create(void);
 void  gpis_obsgp_destroy(void* g);

@@ -2,7 +2,7 @@
 // Flat C-ABI over the CPU restatement so tests/ and bench.py's cpu_baseline leg
 // can drive it through ctypes.  Nothing in gpismap_amd/ may link or load this.
 #include <cstring>
-#include "map3.hpp"
+#include "map2.hpp"
 
 using namespace orc;
 
@@ -80,6 +80,36 @@ void orc3_stats(void* h, long* out6) {
 void orc3_obsgp_query(void* h, const float* vu, int n, float* val, float* var) {
     auto* m = (GPisMap3*)h;
     for (int i = 0; i < n; ++i) m->gpo->test1(vu[2 * i], vu[2 * i + 1], val[i], var[i]);
+}
+
+// ---- map level (2-D) -------------------------------------------------------
+void* orc2_create() { return new GPisMap2(); }
+void orc2_destroy(void* h) { delete (GPisMap2*)h; }
+void orc2_reset(void* h) { ((GPisMap2*)h)->reset(); }
+void orc2_set_threads(void* h, int n) { ((GPisMap2*)h)->nthreads = n; }
+void orc2_update(void* h, const float* theta, const float* range, int n, const float* pose6) {
+    ((GPisMap2*)h)->update(theta, range, n, pose6, 6);
+}
+int orc2_test(void* h, const float* x, int dim, int n, float* res) { return ((GPisMap2*)h)->test(x, dim, n, res) ? 1 : 0; }
+void orc2_test_flags(void* h, const float* x, int n, int* flags) { ((GPisMap2*)h)->testFlags(x, n, flags); }
+int orc2_get_nodes(void* h, float* out7, int cap) {
+    std::vector<float> p; ((GPisMap2*)h)->getAllNodes(p);
+    int n = (int)(p.size() / 7);
+    if (out7 && n <= cap) std::memcpy(out7, p.data(), p.size() * sizeof(float));
+    return n;
+}
+void orc2_stats(void* h, long* out6) {
+    auto* m = (GPisMap2*)h;
+    auto& s = m->stats;
+    out6[0] = s.obsgp_tiles; out6[1] = m->gpo ? m->gpo->n_queries : 0;
+    out6[2] = s.clusters_trained; out6[3] = s.sumK; out6[4] = s.maxK; out6[5] = s.gp_evals;
+}
+int orc2_obsgp_sizes(void* h, int* out, int cap) {
+    auto* m = (GPisMap2*)h;
+    if (!m->gpo) return 0;
+    int n = (int)m->gpo->gps.size();
+    for (int i = 0; i < n && i < cap; ++i) out[i] = m->gpo->gps[i]->n;
+    return n;
 }
 
 // ---- component level -------------------------------------------------------

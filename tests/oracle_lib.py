@@ -47,6 +47,16 @@ def lib():
         L.orc3_get_obs.argtypes = [C.c_void_p, fp, fp]
         L.orc3_obsgp_num_tiles.argtypes = [C.c_void_p]
         L.orc3_obsgp_tile.argtypes = [C.c_void_p, C.c_int, fp, fp, fp]
+        L.orc2_create.restype = C.c_void_p
+        for name in ("orc2_destroy", "orc2_reset"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.orc2_set_threads.argtypes = [C.c_void_p, C.c_int]
+        L.orc2_update.argtypes = [C.c_void_p, fp, fp, C.c_int, fp]
+        L.orc2_test.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, fp]
+        L.orc2_test_flags.argtypes = [C.c_void_p, fp, C.c_int, ip]
+        L.orc2_get_nodes.argtypes = [C.c_void_p, fp, C.c_int]
+        L.orc2_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
+        L.orc2_obsgp_sizes.argtypes = [C.c_void_p, ip, C.c_int]
         L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
         L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.orc_bwd_subst.argtypes = [fp, C.c_int, C.c_int, fp]
@@ -167,3 +177,58 @@ class OracleMap3:
         var = np.zeros(n, dtype=np.float32)
         self.L.orc3_obsgp_query(self.h, _p(vu), n, _p(val), _p(var))
         return val, var
+
+
+class OracleMap2:
+    """Mirror of the reference's mexGPisMap command set ('update', 'test', 'reset') on the CPU oracle."""
+
+    def __init__(self, threads=None):
+        self.L = lib()
+        self.h = C.c_void_p(self.L.orc2_create())
+        if threads:
+            self.L.orc2_set_threads(self.h, threads)
+
+    def close(self):
+        if self.h:
+            self.L.orc2_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def reset(self):
+        self.L.orc2_reset(self.h)
+
+    def update(self, thetas, ranges, pose6):
+        thetas = np.ascontiguousarray(thetas, dtype=np.float32)
+        ranges = np.ascontiguousarray(ranges, dtype=np.float32)
+        pose6 = np.ascontiguousarray(pose6, dtype=np.float32)
+        self.L.orc2_update(self.h, _p(thetas), _p(ranges), ranges.size, _p(pose6))
+
+    def test(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        res = np.zeros((x.shape[0], 6), dtype=np.float32)
+        ok = self.L.orc2_test(self.h, _p(x), 2, x.shape[0], _p(res))
+        return res if ok else None
+
+    def test_flags(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        fl = np.zeros(x.shape[0], dtype=np.int32)
+        self.L.orc2_test_flags(self.h, _p(x), x.shape[0], _p(fl, C.c_int))
+        return fl
+
+    def nodes(self):
+        n = self.L.orc2_get_nodes(self.h, None, 0)
+        out = np.zeros((n, 7), dtype=np.float32)
+        if n:
+            self.L.orc2_get_nodes(self.h, _p(out), n)
+        return out
+
+    def stats(self):
+        a = (C.c_long * 6)()
+        self.L.orc2_stats(self.h, a)
+        return dict(zip(("obsgp_tiles", "obsgp_queries", "clusters_trained", "sumK", "maxK", "gp_evals"), list(a)))
+
+    def obsgp_sizes(self):
+        a = (C.c_int * 64)()
+        n = self.L.orc2_obsgp_sizes(self.h, a, 64)
+        return list(a)[:n]

@@ -85,3 +85,26 @@ def synthetic_grid(n=256):
     zs = np.linspace(0.85, 1.15, n)
     Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
     return np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1).astype(np.float32)
+
+
+def load_gazebo():
+    """data/2D frames 101:100:2801 as demo_gpisMap.m:37-51 feeds them: list of dicts
+    {thetas float32[270], ranges float32[270], pose float32[6] = [x y cos(phi) sin(phi) -sin(phi) cos(phi)]}."""
+    z = np.load(os.path.join(GOLDEN, "gazebo2d_seq.npz"))
+    thetas = z["thetas"].astype(np.float32)
+    frames = []
+    for i in range(z["ranges"].shape[0]):
+        x, y, phi = z["poses"][i]
+        rot = np.array([[np.cos(phi), -np.sin(phi)], [np.sin(phi), np.cos(phi)]])
+        pose = np.concatenate([[x, y], rot.ravel(order="F")]).astype(np.float32)   # single([tr; Rot(:)])
+        frames.append(dict(thetas=thetas, ranges=z["ranges"][i].astype(np.float32), pose=pose))
+    return frames
+
+
+def demo2_grid():
+    """meshgrid(-4.9:0.1:19.9, -14.9:0.1:4.9) flattened MATLAB-style (y fastest): 249 x 199 = 49 551 points
+    (demo_gpisMap.m:29-35)."""
+    xs = -5.0 + 0.1 * np.arange(1, 250)
+    ys = -15.0 + 0.1 * np.arange(1, 200)
+    X, Y = np.meshgrid(xs, ys, indexing="ij")
+    return np.stack([X.ravel(), Y.ravel()], axis=1).astype(np.float32)

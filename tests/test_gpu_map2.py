@@ -1,0 +1,46 @@
+"""End-to-end parity on the bundled 2-D laser sequence (BASELINE configs 1-2): GPisMap
+update()/test() on the HIP path vs the CPU oracle, through the C-ABI (gpis2_*)."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def test_2d_sequence_matches_oracle():
+    import gpismap_amd
+    frames = replay.load_gazebo()
+    grid = replay.demo2_grid()
+    gm = gpismap_amd.GPisMap()
+    om = oracle_lib.OracleMap2()
+    assert gm.test(grid[:10]) is None
+    tos = 3.0 / 1.2 ** 2
+    for i, fr in enumerate(frames):
+        gm.update(fr["thetas"], fr["ranges"], fr["pose"])
+        om.update(fr["thetas"], fr["ranges"], fr["pose"])
+        ng, no = gm.nodes(), om.nodes()
+        assert ng.shape == no.shape, (i, ng.shape, no.shape)
+        assert np.abs(ng - no).max() < 1e-5, (i, float(np.abs(ng - no).max()))
+        if i in (0, 9, 27):
+            rg, ro = gm.test(grid), om.test(grid)
+            fl = om.test_flags(grid)
+            ok = (fl & 6) == 0
+            e_f = rg[ok, 0] - ro[ok, 0]
+            e_g = rg[ok, 1:3] - ro[ok, 1:3]
+            rmse = float(np.sqrt(np.mean(e_f ** 2)))
+            print("frame %d: %d pts, %d clusters, %d masked, SDF rmse %.3e max %.3e grad max %.3e var_f max %.3e var_g rel %.3e"
+                  % (fr and i + 1, ng.shape[0], gm.stats()["clusters"], int((~ok).sum()), rmse, float(np.abs(e_f).max()),
+                     float(np.abs(e_g).max()), float(np.abs(rg[ok, 3] - ro[ok, 3]).max()),
+                     float(np.abs(rg[ok, 4:6] - ro[ok, 4:6]).max() / tos)))
+            assert rmse < 1e-5 and np.abs(e_f).max() < 1e-4
+            assert np.abs(e_g).max() < 1e-3
+            assert np.abs(rg[ok, 3] - ro[ok, 3]).max() < 1e-4
+            assert np.abs(rg[ok, 4:6] - ro[ok, 4:6]).max() / tos < 1e-4
+    # known answers of SURVEY.md 8(c) for the final frame
+    ro = om.test(grid)
+    assert int((ro[:, 3] < 0.4).sum()) == 18720
+    rg = gm.test(grid)
+    assert abs(int((rg[:, 3] < 0.4).sum()) - 18720) <= 3
+    assert abs(float(rg[:, 0].mean()) - (-0.0838)) < 1e-4
