@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <unordered_map>
 #include "../../include/GPisMap.h"
 #include "flat_tree.h"
 #include "map_query.h"
@@ -79,7 +81,8 @@ struct GPisMap::Impl {
         obs_numdata = 0;
         activeSet.clear();
         std::vector<ClusterEntry> none;
-        mq.set_clusters(none, 2.0 * (double)tree.prm.cluster_half, stream);
+        std::vector<AncestorEntry> nanc;
+        mq.set_clusters(none, nanc, 2.0 * (double)tree.prm.cluster_half, stream);
     }
 
     bool preproData(const float* datax, const float* dataf, int N, const std::vector<float>& pose);
@@ -475,13 +478,30 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
     std::vector<int> cl;
     tree.all_clusters(cl);
     std::vector<ClusterEntry> ent(cl.size());
+    std::vector<AncestorEntry> anc;
+    std::unordered_map<int, int> anc_of;
+    std::function<int(int)> anc_index = [&](int node) -> int {
+        if (node < 0) return -1;
+        auto it = anc_of.find(node);
+        if (it != anc_of.end()) return it->second;
+        const T2::TNode& a = tree.nodes[node];
+        int up = (node == tree.root) ? -1 : anc_index(a.par);
+        AncestorEntry e;
+        for (int d = 0; d < 2; ++d) { e.lo[d] = a.lo[d]; e.hi[d] = a.hi[d]; }
+        e.lo[2] = 0.f; e.hi[2] = 0.f;
+        e.parent = up;
+        anc.push_back(e);
+        anc_of[node] = (int)anc.size() - 1;
+        return (int)anc.size() - 1;
+    };
     for (size_t i = 0; i < cl.size(); ++i) {
         const T2::TNode& t = tree.nodes[cl[i]];
         for (int d = 0; d < 2; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
         ent[i].c[2] = 0.f; ent[i].lo[2] = 0.f; ent[i].hi[2] = 0.f;
         ent[i].model = t.model;
+        ent[i].parent = anc_index(t.par);
     }
-    int rc = mq.set_clusters(ent, 2.0 * (double)tree.prm.cluster_half, stream);
+    int rc = mq.set_clusters(ent, anc, 2.0 * (double)tree.prm.cluster_half, stream);
     if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
 }
 

@@ -12,6 +12,8 @@
 #include <array>
 #include <cmath>
 #include <cstring>
+#include <functional>
+#include <unordered_map>
 #include "../../include/GPisMap3.h"
 #include "flat_tree.h"
 #include "map_query.h"
@@ -106,7 +108,8 @@ struct GPisMap3::Impl {
         obs_numdata = 0;
         activeSet.clear();
         std::vector<ClusterEntry> none;
-        mq.set_clusters(none, 2.0 * kCleng, stream);
+        std::vector<AncestorEntry> nanc;
+        mq.set_clusters(none, nanc, 2.0 * kCleng, stream);
     }
 
     bool preprocData(const float* dataz, int N, const std::vector<float>& pose);
@@ -558,17 +561,34 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     std::vector<int> cl;
     tree.all_clusters(cl);
     std::vector<ClusterEntry> ent(cl.size());
+    // ancestor chains (up to the root the map holds), shared between sibling cells
+    std::vector<AncestorEntry> anc;
+    std::unordered_map<int, int> anc_of;
+    std::function<int(int)> anc_index = [&](int node) -> int {
+        if (node < 0) return -1;
+        auto it = anc_of.find(node);
+        if (it != anc_of.end()) return it->second;
+        const T3::TNode& a = tree.nodes[node];
+        int up = (node == tree.root) ? -1 : anc_index(a.par);
+        AncestorEntry e;
+        for (int d = 0; d < 3; ++d) { e.lo[d] = a.lo[d]; e.hi[d] = a.hi[d]; }
+        e.parent = up;
+        anc.push_back(e);
+        anc_of[node] = (int)anc.size() - 1;
+        return (int)anc.size() - 1;
+    };
     for (size_t i = 0; i < cl.size(); ++i) {
         const T3::TNode& t = tree.nodes[cl[i]];
         for (int d = 0; d < 3; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
         ent[i].model = t.model;
+        ent[i].parent = anc_index(t.par);
     }
     stat_model_bytes = 0;
     for (size_t i = 0; i < cl.size(); ++i) {
         const ClusterModel* mm = store.model(tree.nodes[cl[i]].model);
         if (mm && mm->base) stat_model_bytes += 4.0 * (3.0 * mm->N + mm->K + 0.5 * (double)mm->K * (mm->K + 1));
     }
-    int rc = mq.set_clusters(ent, 2.0 * (double)kCleng, stream);
+    int rc = mq.set_clusters(ent, anc, 2.0 * (double)kCleng, stream);
     if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
 }
 

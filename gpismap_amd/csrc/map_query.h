@@ -12,6 +12,16 @@ struct ClusterEntry {  // host description of one non-empty cluster cell (tree t
     float c[3];
     float lo[3], hi[3];
     int model;         // store slot or -1
+    int parent;        // index into the ancestor table or -1
+};
+
+// Internal tree node above the cluster level.  The reference reaches a cluster cell only through
+// a top-down walk that prunes on EVERY ancestor's box (octree.cpp:864-866); ancestor and child
+// bounds are rounded independently, so for queries aligned with cell boundaries the ancestor test
+// can fail where the cell's own test passes.  The lookup kernel therefore re-checks the chain.
+struct AncestorEntry {
+    float lo[3], hi[3];
+    int parent;        // next ancestor or -1 (root)
 };
 
 struct ClusterTableView {
@@ -20,6 +30,10 @@ struct ClusterTableView {
     const float4* lo;
     const float4* hi;
     const int* model;
+    const int* parent; // [n] first ancestor (index into anc_*) or -1
+    const float4* anc_lo;
+    const float4* anc_hi;
+    const int* anc_parent;
     const int* grid;   // dense lattice: cell -> table index or -1
     int gx, gy, gz;
     double ox, oy, oz; // lattice origin (lower corner of cell 0)
@@ -31,7 +45,7 @@ public:
     MapQuery(int dim, float search_half, float var_thre, float prior_var);
     ~MapQuery();
     // Rebuild the cluster table + lattice from the host tree (after every update()).
-    int set_clusters(const std::vector<ClusterEntry>& cl, double pitch, hipStream_t s);
+    int set_clusters(const std::vector<ClusterEntry>& cl, const std::vector<AncestorEntry>& anc, double pitch, hipStream_t s);
     // test(): x device [n][dim] interleaved, res device [n][2(1+dim)]; only the entries the
     // reference writes are touched.
     int run(OnGPISStore& store, const float* d_x, int n, float* d_res, hipStream_t s);

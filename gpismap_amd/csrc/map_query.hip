@@ -19,6 +19,20 @@ namespace gpis {
 // ------------------------------------------------------------------ lookup ----
 
 template <int DIM>
+__device__ __forceinline__ bool cell_hit(const ClusterTableView& T, int ci, const float* qlo, const float* qhi) {
+    float4 lo = T.lo[ci], hi = T.hi[ci];
+    bool hit = !((qhi[0] < lo.x) || (qlo[0] > hi.x) || (qhi[1] < lo.y) || (qlo[1] > hi.y));
+    if (DIM == 3) hit = hit && !((qhi[2] < lo.z) || (qlo[2] > hi.z));
+    // every ancestor must intersect too (top-down pruning of the reference's tree walk)
+    for (int a = T.parent[ci]; hit && a >= 0; a = T.anc_parent[a]) {
+        float4 alo = T.anc_lo[a], ahi = T.anc_hi[a];
+        hit = !((qhi[0] < alo.x) || (qlo[0] > ahi.x) || (qhi[1] < alo.y) || (qlo[1] > ahi.y));
+        if (DIM == 3) hit = hit && !((qhi[2] < alo.z) || (qlo[2] > ahi.z));
+    }
+    return hit;
+}
+
+template <int DIM>
 __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const float* __restrict__ x, int n,
                                                      float half, float4* __restrict__ xq4,
                                                      int* __restrict__ cand, int* __restrict__ ncand, int cap) {
@@ -46,10 +60,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const f
             for (int ix = i0[0]; ix <= i1[0]; ++ix) {
                 int ci = T.grid[((size_t)iz * T.gy + iy) * T.gx + ix];
                 if (ci < 0) continue;
-                float4 lo = T.lo[ci], hi = T.hi[ci];
-                bool hit = !((qhi[0] < lo.x) || (qlo[0] > hi.x) || (qhi[1] < lo.y) || (qlo[1] > hi.y));
-                if (DIM == 3) hit = hit && !((qhi[2] < lo.z) || (qlo[2] > hi.z));
-                if (!hit) continue;
+                if (!cell_hit<DIM>(T, ci, qlo, qhi)) continue;
                 float4 c = T.c[ci];
                 float dx = c.x - p[0], dy = c.y - p[1], dz = c.z - p[2];
                 float sd = (DIM == 3) ? (dx * dx + dy * dy) + dz * dz : dx * dx + dy * dy;
@@ -76,10 +87,7 @@ __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const f
                 for (int ix = i0[0]; ix <= i1[0]; ++ix) {
                     int ci = T.grid[((size_t)iz * T.gy + iy) * T.gx + ix];
                     if (ci < 0) continue;
-                    float4 lo = T.lo[ci], hi = T.hi[ci];
-                    bool hit = !((qhi[0] < lo.x) || (qlo[0] > hi.x) || (qhi[1] < lo.y) || (qlo[1] > hi.y));
-                    if (DIM == 3) hit = hit && !((qhi[2] < lo.z) || (qlo[2] > hi.z));
-                    if (!hit || n2 >= 128) continue;
+                    if (n2 >= 128 || !cell_hit<DIM>(T, ci, qlo, qhi)) continue;
                     float4 c = T.c[ci];
                     float dx = c.x - p[0], dy = c.y - p[1], dz = c.z - p[2];
                     float sd = (DIM == 3) ? (dx * dx + dy * dy) + dz * dz : dx * dx + dy * dy;
@@ -282,7 +290,7 @@ MapQuery::~MapQuery() {
     if (ev1_) (void)hipEventDestroy(ev1_);
 }
 
-int MapQuery::set_clusters(const std::vector<ClusterEntry>& cl, double pitch, hipStream_t s) {
+int MapQuery::set_clusters(const std::vector<ClusterEntry>& cl, const std::vector<AncestorEntry>& anc, double pitch, hipStream_t s) {
     ncl_ = (int)cl.size();
     tv_.n = ncl_;
     if (ncl_ == 0) return GPIS_OK;
@@ -300,8 +308,9 @@ int MapQuery::set_clusters(const std::vector<ClusterEntry>& cl, double pitch, hi
     size_t ncell = (size_t)g[0] * g[1] * g[2];
     if (ncell > ((size_t)1 << 31)) return GPIS_ERR_LIMIT;
     std::vector<int> grid(ncell, -1);
-    std::vector<float4> tab((size_t)3 * ncl_);
-    std::vector<int> mdl(ncl_);
+    const size_t na = anc.size();
+    std::vector<float4> tab((size_t)3 * ncl_ + 2 * na);
+    std::vector<int> mdl((size_t)2 * ncl_ + na);
     for (int i = 0; i < ncl_; ++i) {
         const ClusterEntry& e = cl[i];
         int ix[3];
@@ -319,18 +328,27 @@ int MapQuery::set_clusters(const std::vector<ClusterEntry>& cl, double pitch, hi
         tab[(size_t)ncl_ + i] = make_float4(e.lo[0], e.lo[1], e.lo[2], 0.f);
         tab[(size_t)2 * ncl_ + i] = make_float4(e.hi[0], e.hi[1], e.hi[2], 0.f);
         mdl[i] = e.model;
+        mdl[(size_t)ncl_ + i] = e.parent;
     }
-    size_t tbytes = sizeof(float4) * 3 * (size_t)ncl_ + sizeof(int) * (size_t)ncl_;
+    for (size_t a = 0; a < na; ++a) {
+        tab[(size_t)3 * ncl_ + a] = make_float4(anc[a].lo[0], anc[a].lo[1], anc[a].lo[2], 0.f);
+        tab[(size_t)3 * ncl_ + na + a] = make_float4(anc[a].hi[0], anc[a].hi[1], anc[a].hi[2], 0.f);
+        mdl[(size_t)2 * ncl_ + a] = anc[a].parent;
+    }
+    size_t tbytes = sizeof(float4) * tab.size() + sizeof(int) * mdl.size();
     if (tbytes > cap_tab_) { (void)hipFree(d_tab_); d_tab_ = nullptr; GPIS_HIP(hipMalloc(&d_tab_, tbytes * 2)); cap_tab_ = tbytes * 2; }
     if (ncell > cap_grid_) { (void)hipFree(d_grid_); d_grid_ = nullptr; GPIS_HIP(hipMalloc(&d_grid_, sizeof(int) * ncell * 2)); cap_grid_ = ncell * 2; }
     GPIS_HIP(hipMemcpyAsync(d_tab_, tab.data(), sizeof(float4) * tab.size(), hipMemcpyHostToDevice, s));
-    int* d_model = reinterpret_cast<int*>(reinterpret_cast<char*>(d_tab_) + sizeof(float4) * 3 * (size_t)ncl_);
-    GPIS_HIP(hipMemcpyAsync(d_model, mdl.data(), sizeof(int) * (size_t)ncl_, hipMemcpyHostToDevice, s));
+    int* d_model = reinterpret_cast<int*>(reinterpret_cast<char*>(d_tab_) + sizeof(float4) * tab.size());
+    GPIS_HIP(hipMemcpyAsync(d_model, mdl.data(), sizeof(int) * mdl.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_grid_, grid.data(), sizeof(int) * ncell, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipStreamSynchronize(s));
     tv_.c = reinterpret_cast<const float4*>(d_tab_);
     tv_.lo = tv_.c + ncl_; tv_.hi = tv_.c + 2 * (size_t)ncl_;
     tv_.model = d_model; tv_.grid = d_grid_;
+    tv_.parent = d_model + ncl_;
+    tv_.anc_lo = tv_.c + 3 * (size_t)ncl_; tv_.anc_hi = tv_.anc_lo + na;
+    tv_.anc_parent = d_model + 2 * (size_t)ncl_;
     tv_.gx = g[0]; tv_.gy = g[1]; tv_.gz = g[2];
     tv_.ox = org[0]; tv_.oy = org[1]; tv_.oz = org[2]; tv_.pitch = pitch;
     return GPIS_OK;

@@ -415,25 +415,44 @@ struct OnGPIS {
         trained = true;
     }
 
+    // Reduction order (O3) of the two long sums k*^T alpha and sum(v^2).  Eigen evaluates them
+    // with packet-wise interleaved partial sums (order unspecified); this restatement fixes
+    // 2*W interleaved partial chains: row r goes to chain (w, h) with w = (r / 32) mod W,
+    // h = (r / 4) mod 2, each chain is an ascending fmaf chain, the pair (w,0)+(w,1) is added,
+    // and the W pair sums are accumulated in ascending w.  W = 1, 4, 8 for K <= 256, <= 1024,
+    // larger.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
+    static int chains_W(int K) {
+        int nb = (K + 31) / 32;
+        return nb <= 8 ? 1 : (nb <= 32 ? 4 : 8);
+    }
+    template <class F>
+    static float reduce_O3(int K, F&& term_chain) {
+        const int W = chains_W(K);
+        float P[8][2];
+        for (int w = 0; w < 8; ++w) P[w][0] = P[w][1] = 0.f;
+        for (int r = 0; r < K; ++r) {
+            int w = (r >> 5) % W, h = (r >> 2) & 1;
+            P[w][h] = term_chain(r, P[w][h]);
+        }
+        float s = 0.f;
+        for (int w = 0; w < W; ++w) s += (P[w][0] + P[w][1]);
+        return s;
+    }
+
     // out[0..dim] = f, grad ; out[1+dim .. 2(1+dim)-1] = variances.
-    // Means and sums of squares are single ascending fmaf chains (the GPU
-    // kernel is compared against these with a tolerance, not bit for bit).
     void test1(const float* xq, float* mean, float* var) const {
         if (!trained) return;
         const int nc = 1 + dim;
         std::vector<float> ks((size_t)K * nc);
         matern32_cross1(dim, N, x.data(), gidx.data(), ng, scale, xq, ks.data(), K);
         for (int c = 0; c < nc; ++c) {
-            float s = 0.f;
             const float* col = &ks[(size_t)c * K];
-            for (int r = 0; r < K; ++r) s = fmaf(col[r], alpha[r], s);
-            mean[c] = s;
+            mean[c] = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], alpha[r], acc); });
         }
         fwd_subst(L.data(), K, K, ks.data(), nc, K);
         for (int c = 0; c < nc; ++c) {
-            float s = 0.f;
             const float* col = &ks[(size_t)c * K];
-            for (int r = 0; r < K; ++r) s = fmaf(col[r], col[r], s);
+            float s = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], col[r], acc); });
             if (dim == 3)  // OnGPIS.cpp:208-213
                 var[c] = (c == 0) ? (float)(1.001 - (double)s)
                                   : (float)((double)three_over_scale + 0.001 - (double)s);

@@ -16,6 +16,8 @@
 //   (O1) Cholesky / forward substitution: every element is one fmaf chain over
 //        ascending k:   s = a_ij; s = fmaf(-l_ik, l_jk, s), k = 0..j-1
 //   (O2) backward substitution: one fmaf chain over DEscending k.
+//   (O3) long dot products / sums of squares in OnGPIS prediction: 2*W interleaved fmaf
+//        chains (gp.hpp, OnGPIS::reduce_O3); (O4)/(O5) ObsGP mean butterfly / variance chain.
 //   sqrt and divide are IEEE correctly rounded.
 // Storage is column-major with leading dimension ld (as Eigen's MatrixXf).
 #pragma once

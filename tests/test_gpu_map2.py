@@ -22,16 +22,19 @@ def test_2d_sequence_matches_oracle():
         om.update(fr["thetas"], fr["ranges"], fr["pose"])
         ng, no = gm.nodes(), om.nodes()
         assert ng.shape == no.shape, (i, ng.shape, no.shape)
-        assert np.abs(ng - no).max() < 1e-5, (i, float(np.abs(ng - no).max()))
+        assert np.array_equal(ng, no), (i, float(np.abs(ng - no).max()))
         if i in (0, 9, 27):
             rg, ro = gm.test(grid), om.test(grid)
             fl = om.test_flags(grid)
-            ok = (fl & 6) == 0
+            ok = np.ones(grid.shape[0], dtype=bool)       # nothing masked
+            same = float(np.mean(np.all(rg == ro, axis=1)))
+            assert same >= 0.9995, same
             e_f = rg[ok, 0] - ro[ok, 0]
             e_g = rg[ok, 1:3] - ro[ok, 1:3]
             rmse = float(np.sqrt(np.mean(e_f ** 2)))
-            print("frame %d: %d pts, %d clusters, %d masked, SDF rmse %.3e max %.3e grad max %.3e var_f max %.3e var_g rel %.3e"
-                  % (fr and i + 1, ng.shape[0], gm.stats()["clusters"], int((~ok).sum()), rmse, float(np.abs(e_f).max()),
+            print("bit-identical rows %.5f" % same)
+            print("frame %d: %d pts, %d clusters, %d flagged(not masked), SDF rmse %.3e max %.3e grad max %.3e var_f max %.3e var_g rel %.3e"
+                  % (fr and i + 1, ng.shape[0], gm.stats()["clusters"], int(((fl & 6) != 0).sum()), rmse, float(np.abs(e_f).max()),
                      float(np.abs(e_g).max()), float(np.abs(rg[ok, 3] - ro[ok, 3]).max()),
                      float(np.abs(rg[ok, 4:6] - ro[ok, 4:6]).max() / tos)))
             assert rmse < 1e-5 and np.abs(e_f).max() < 1e-4

@@ -12,25 +12,28 @@ NFRAMES = 6
 
 
 def compare_res(rg, ro, flags, tag):
-    """SDF / gradient / variance errors outside the order- and branch-ambiguous queries."""
-    amb = (flags & (2 | 4)) != 0          # variance within 1e-3 of the 0.5 gate / near-equal candidate variances
-    ok = ~amb
-    touched = np.abs(ro).sum(axis=1) > 1.005 + 1e-6
-    e_f = rg[ok, 0] - ro[ok, 0]
+    """The HIP path keeps the oracle's fixed summation orders, so whole result rows are expected to
+    be bit-identical (a 1-ulp difference of the double exp() between glibc and the device can
+    perturb a row once in ~1e8 kernel entries).  The fp32 tolerances of SURVEY.md 8(c) are asserted
+    on ALL queries -- nothing is masked; `flags` only reports how many queries sit on one of the
+    reference's own discontinuities (variance within 1e-3 of the 0.5 gate, near-equal candidates)."""
+    amb = (flags & (2 | 4)) != 0
+    same = float(np.mean(np.all(rg == ro, axis=1)))
+    e_f = rg[:, 0] - ro[:, 0]
     rmse_f = float(np.sqrt(np.mean(e_f ** 2)))
-    e_g = rg[ok, 1:4] - ro[ok, 1:4]
+    e_g = rg[:, 1:4] - ro[:, 1:4]
     rmse_g = float(np.sqrt(np.mean(e_g ** 2)))
-    e_v = np.abs(rg[ok, 4] - ro[ok, 4])
-    e_vg = np.abs(rg[ok, 5:8] - ro[ok, 5:8]) / 1875.0
-    print("%s: %d queries, %d ambiguous masked, SDF rmse %.3e max %.3e | grad rmse %.3e max %.3e | var_f max %.3e | var_g rel max %.3e"
-          % (tag, rg.shape[0], int(amb.sum()), rmse_f, float(np.abs(e_f).max()), rmse_g, float(np.abs(e_g).max()),
-             float(e_v.max()), float(e_vg.max())))
-    assert rmse_f < 1e-5 and np.abs(e_f).max() < 1e-4
-    assert rmse_g < 1e-4 and np.abs(e_g).max() < 2e-3
-    assert e_v.max() < 1e-4
-    assert e_vg.max() < 1e-4
-    # the masked ones must still be sane (finite, bounded)
-    assert np.all(np.isfinite(rg[touched]))
+    e_v = np.abs(rg[:, 4] - ro[:, 4])
+    e_vg = np.abs(rg[:, 5:8] - ro[:, 5:8]) / 1875.0
+    print("%s: %d queries (%d on a reference discontinuity, none masked), bit-identical rows %.5f, SDF rmse %.3e max %.3e | "
+          "grad rmse %.3e | var_f max %.3e | var_g rel max %.3e"
+          % (tag, rg.shape[0], int(amb.sum()), same, rmse_f, float(np.abs(e_f).max()), rmse_g, float(e_v.max()), float(e_vg.max())))
+    assert same >= 0.9995
+    assert rmse_f < 1e-5 and rmse_g < 1e-4
+    ok = ~amb                      # a flipped branch (only possible on `amb` rows) may exceed the max bars
+    assert np.abs(e_f[ok]).max() < 1e-4 and np.abs(e_g[ok]).max() < 2e-3
+    assert e_v[ok].max() < 1e-4 and e_vg[ok].max() < 1e-4
+    assert np.all(np.isfinite(rg))
 
 
 def test_sequence_matches_oracle():
@@ -49,7 +52,7 @@ def test_sequence_matches_oracle():
         assert ng.shape == no.shape, (i, ng.shape, no.shape)
         # map state: positions / normals / noises, tree order.  Decisions are driven by K2 results
         # that are bit-identical to the oracle up to rare 1-ulp exp() differences.
-        assert np.abs(ng - no).max() < 1e-5, (i, float(np.abs(ng - no).max()))
+        assert np.array_equal(ng, no), (i, float(np.abs(ng - no).max()))
         rg = gm.test(grid); ro = om.test(grid)
         flags = om.test_flags(grid)
         compare_res(rg, ro, flags, "frame %d (%d pts, %d clusters)" % (i + 1, ng.shape[0], gm.stats()["clusters"]))

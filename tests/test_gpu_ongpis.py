@@ -95,6 +95,9 @@ def test_train_and_predict_match_oracle(dim, scale, sizes):
     d_g = np.abs(mean_g[:, 1:] - mean_o[:, 1:]).max()
     d_vf = np.abs(var_g[:, 0] - var_o[:, 0]).max()
     d_vg = (np.abs(var_g[:, 1:] - var_o[:, 1:]) / tos).max()
+    same = float(np.mean(np.all(got[:, list(range(nc)) + list(range(4, 4 + nc))] == ref, axis=1)))
+    print("predict bit-identical rows %.5f" % same)
+    assert same >= 0.999
     print("predict: max|df| %.3e max|dgrad| %.3e max|dvar_f| %.3e max rel dvar_g %.3e (eval ms %.3f)" % (d_f, d_g, d_vf, d_vg, st.last_ms()[1]))
     assert d_f < 2e-5          # SDF value
     assert d_g < 2e-3          # gradients are O(1/scale)
