@@ -139,24 +139,24 @@ __global__ void hist_kernel(const int* __restrict__ jm, int njobs, int* __restri
 }
 
 // single block: exclusive scan of job counts; per-class tile bases.  tot[0..3] = tiles per
-// class, tot[4] = total jobs, tot[8..11] = class tile offsets.
+// class (tot[0..5]), tot[6] = total jobs, tot[8..13] = class tile offsets.
 __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restrict__ models, int nmodels,
                                                     const int* __restrict__ cnt, int* __restrict__ base,
                                                     int* __restrict__ tbase, int* __restrict__ cursor,
                                                     int* __restrict__ tot, unsigned long long* __restrict__ flops) {
     __shared__ int sj[1024];
     __shared__ unsigned long long sf[1024];
-    __shared__ int st[4][1024];
+    __shared__ int st[ONGPIS_NCLASS][1024];
     const int tid = threadIdx.x;
     const int chunk = (nmodels + 1023) / 1024;
     const int m0 = tid * chunk, m1 = min(nmodels, m0 + chunk);
-    int aj = 0, at[4] = {0, 0, 0, 0};
+    int aj = 0, at[ONGPIS_NCLASS] = {0};
     unsigned long long af = 0;
     for (int m = m0; m < m1; ++m) {
         int c = cnt[m];
         if (c > 0) {
             int nb = models[m].nb;
-            int cls = nb <= 8 ? 0 : (nb <= 32 ? 1 : (nb <= 64 ? 2 : 3));
+            int cls = ongpis_class_of_nb(nb);
             aj += c; at[cls] += (c + 7) / 8;
             // algorithmic flops of one evaluation: (1+d) K^2 + 2 (1+d) K + 25 N
             unsigned long long K = models[m].K, N = models[m].N, d1 = 1 + models[m].dim;
@@ -164,29 +164,30 @@ __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restri
         }
     }
     sj[tid] = aj; sf[tid] = af;
-    for (int k = 0; k < 4; ++k) st[k][tid] = at[k];
+    for (int k = 0; k < ONGPIS_NCLASS; ++k) st[k][tid] = at[k];
     __syncthreads();
     if (tid == 0) {
-        int rj = 0, rt[4] = {0, 0, 0, 0};
+        int rj = 0, rt[ONGPIS_NCLASS] = {0};
         for (int i = 0; i < 1024; ++i) {
             int t = sj[i]; sj[i] = rj; rj += t;
-            for (int k = 0; k < 4; ++k) { int u = st[k][i]; st[k][i] = rt[k]; rt[k] += u; }
+            for (int k = 0; k < ONGPIS_NCLASS; ++k) { int u = st[k][i]; st[k][i] = rt[k]; rt[k] += u; }
         }
-        tot[4] = rj;
+        tot[6] = rj;
         unsigned long long fs = 0;
         for (int i = 0; i < 1024; ++i) fs += sf[i];
         flops[0] = fs;
         int off = 0;
-        for (int k = 0; k < 4; ++k) { tot[k] = rt[k]; tot[8 + k] = off; off += rt[k]; }
+        for (int k = 0; k < ONGPIS_NCLASS; ++k) { tot[k] = rt[k]; tot[8 + k] = off; off += rt[k]; }
     }
     __syncthreads();
-    int rj = sj[tid], rt[4] = {st[0][tid], st[1][tid], st[2][tid], st[3][tid]};
+    int rj = sj[tid], rt[ONGPIS_NCLASS];
+    for (int k = 0; k < ONGPIS_NCLASS; ++k) rt[k] = st[k][tid];
     for (int m = m0; m < m1; ++m) {
         int c = cnt[m];
         base[m] = rj; cursor[m] = 0;
         if (c > 0) {
             int nb = models[m].nb;
-            int cls = nb <= 8 ? 0 : (nb <= 32 ? 1 : (nb <= 64 ? 2 : 3));
+            int cls = ongpis_class_of_nb(nb);
             tbase[m] = rt[cls];
             rt[cls] += (c + 7) / 8;
             rj += c;
@@ -215,7 +216,7 @@ __global__ void tiles_kernel(const ClusterModel* __restrict__ models, int nmodel
     int c = cnt[m];
     if (c <= 0) return;
     int nb = models[m].nb;
-    int cls = nb <= 8 ? 0 : (nb <= 32 ? 1 : (nb <= 64 ? 2 : 3));
+    int cls = ongpis_class_of_nb(nb);
     int t0 = tot[8 + cls] + tbase[m];
     int nt = (c + 7) / 8;
     for (int i = threadIdx.x; i < nt; i += blockDim.x) {
@@ -278,7 +279,7 @@ __global__ void prior_only_kernel(int n, int nc2, int vidx, float prior_var, flo
 
 // --------------------------------------------------------------- host side ----
 MapQuery::MapQuery(int dim, float search_half, float var_thre, float prior_var)
-    : dim_(dim), search_half_(search_half), var_thre_(var_thre), prior_var_(prior_var), h_maxN_(4, 0) {
+    : dim_(dim), search_half_(search_half), var_thre_(var_thre), prior_var_(prior_var), h_maxN_(ONGPIS_NCLASS, 0) {
     std::memset(&tv_, 0, sizeof(tv_));
 }
 
@@ -405,21 +406,21 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     int tot[20];
     GPIS_HIP(hipMemcpyAsync(tot, d_tot_, sizeof(int) * 20, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
-    last_evals += tot[4];
+    last_evals += tot[6];
     { unsigned long long f; std::memcpy(&f, tot + 16, sizeof(f)); last_flops += (long long)f; }
-    for (int c = 0; c < 4; ++c) if (tot[c] > 0) ++last_launches;
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) if (tot[c] > 0) ++last_launches;
     if (profile) {
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
     }
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) {
         int nt = tot[c];
         if (nt <= 0) continue;
         if (tot[8 + c] + nt > tile_cap_) return GPIS_ERR_STATE;
         EvalArgs a;
         a.models = store.d_models(); a.xq = d_xq_;
         a.tile_model = t_model + tot[8 + c]; a.tile_off = t_off + tot[8 + c]; a.tile_cnt = t_cnt + tot[8 + c];
-        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1;
+        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.lds_model = 1;
         int rc = ongpis_eval_launch(c, nt, h_maxN_[c], a, s);
         if (rc) return rc;
     }

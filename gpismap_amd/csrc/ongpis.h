@@ -104,9 +104,15 @@ struct EvalArgs {
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
     int use_table;           // exp table in LDS (else recompute per entry)
+    int lds_model;           // alpha / rowinfo / x4 staged in LDS (set by ongpis_eval_launch)
+    int dbg;                 // timing ablations (env GPIS_K4_DBG; results are wrong when non-zero)
 };
-// wclass = ongpis_eval_class(nb): 0 -> 1 wave (nb <= 8), 1 -> 4 waves (<= 32), 2 -> 8 waves (<= 64),
-// 3 -> 8 waves x 12 tiles (<= 96); -1 -> cluster too large for this build (K > 3072)
+// K4 size classes by nb = ceil(K/32): 0: nb<=4 (1 wave x 4 tiles), 1: <=8 (2x4), 2: <=16 (4x4),
+// 3: <=32 (4x8), 4: <=64 (8x8), 5: <=96 (8x12); -1 -> cluster too large for this build (K > 3072)
+#define ONGPIS_NCLASS 6
+__host__ __device__ inline int ongpis_class_of_nb(int nb) {
+    return nb <= 4 ? 0 : (nb <= 8 ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : (nb <= 64 ? 4 : 5))));
+}
 int ongpis_eval_class(int nb);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args, hipStream_t s);
 

@@ -160,8 +160,8 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_job_model[a] < h_job_model[b]; });
     std::vector<int> jq(njobs), jo(njobs);
-    std::vector<int> tmodel[4], toff[4], tcnt[4];
-    int maxN[4] = {0, 0, 0, 0};
+    std::vector<int> tmodel[ONGPIS_NCLASS], toff[ONGPIS_NCLASS], tcnt[ONGPIS_NCLASS];
+    int maxN[ONGPIS_NCLASS] = {0};
     for (int i = 0; i < njobs;) {
         int mslot = h_job_model[order[i]];
         const ClusterModel* m = model(mslot);
@@ -178,7 +178,7 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         i = e;
     }
     size_t ntl = 0;
-    for (int c = 0; c < 4; ++c) ntl += tmodel[c].size();
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) ntl += tmodel[c].size();
     size_t need = 2 * (size_t)njobs + 3 * ntl;
     if ((int)need > cap_ej_) {
         (void)hipFree(d_ej_); d_ej_ = nullptr;
@@ -192,8 +192,8 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
     GPIS_HIP(hipMemcpyAsync(d_jq, jq.data(), sizeof(int) * njobs, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jo, jo.data(), sizeof(int) * njobs, hipMemcpyHostToDevice, s));
     std::vector<int> tl;
-    size_t base[4];
-    for (int c = 0; c < 4; ++c) {
+    size_t base[ONGPIS_NCLASS];
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) {
         base[c] = tl.size();
         tl.insert(tl.end(), tmodel[c].begin(), tmodel[c].end());
         tl.insert(tl.end(), toff[c].begin(), toff[c].end());
@@ -204,13 +204,13 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
     }
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) {
         int nt = (int)tmodel[c].size();
         if (!nt) continue;
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = 1;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = 1; a.lds_model = 1;
         rc = ongpis_eval_launch(c, nt, maxN[c], a, s);
         if (rc) return rc;
     }

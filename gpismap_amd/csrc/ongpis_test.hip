@@ -18,9 +18,18 @@
 //     v_mfma_f32_32x32x2_f32, streaming L_bc from L2/HBM exactly once.
 // Each L element is read once per workgroup and used for 32 columns.  The
 // per-element operation order is the ascending-k fmaf chain of dev_common.h.
+#include <algorithm>
+#include <cstdlib>
 #include "ongpis.h"
 
 namespace gpis {
+
+// Pointers read out of a ClusterModel live in global memory; say so, otherwise the compiler must
+// emit flat_load (LDS-or-global at run time), which counts on both wait counters.
+typedef const float __attribute__((address_space(1))) * gfptr;
+typedef const int __attribute__((address_space(1))) * giptr;
+typedef const float4 __attribute__((address_space(1))) * gf4ptr;
+typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // explicit LDS: volatile generic pointers become flat loads
 
 __device__ __forceinline__ int rowmap_t(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
@@ -40,7 +49,7 @@ __device__ __forceinline__ void diag_load(DiagCol& c, const float* Lc, int i, in
         if (8 * g + 7 > i) c.g[g] = p[2 * g];  // compile-time prune (i is a constant after unrolling)
     c.d = Lc[i * 32 + i];
 }
-__device__ __forceinline__ void diag_solve32(float (&v)[16], const float* Lc, int h, int l31) {
+__device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) {
     DiagCol cur, nxt;
     diag_load(cur, Lc, 0, h);
 #pragma unroll
@@ -48,7 +57,10 @@ __device__ __forceinline__ void diag_solve32(float (&v)[16], const float* Lc, in
         if (i + 1 < 32) diag_load(nxt, Lc, i + 1, h);
         const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
         float cand = v[ri] / cur.d;
-        float vi = __shfl(cand, l31 + 32 * hi_);
+        // broadcast row i from the half that owns it: v_permlane32_swap gives {low-half copy, high-half copy}
+        unsigned cu = __float_as_uint(cand);
+        auto sw = __builtin_amdgcn_permlane32_swap(cu, cu, false, false);
+        float vi = __uint_as_float(hi_ ? sw[1] : sw[0]);
         v[ri] = (h == hi_) ? vi : v[ri];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -66,8 +78,11 @@ __device__ __forceinline__ void diag_solve32(float (&v)[16], const float* Lc, in
     }
 }
 
-template <int W, int NBW>
-__global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(EvalArgs A) {
+// Size classes (block rows nb = ceil(K/32)): W waves x NBW tiles per wave.
+//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 4x8   <= 64: 8x8   <= 96: 8x12
+template <int W, int NBW, int MINW>
+__global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
+    constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -76,15 +91,20 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
     const int N = m.N, K = m.K, ld = m.ld, nb = m.nb, dim = m.dim;
     const int joff = A.tile_off[tile], jcnt = A.tile_cnt[tile];
 
-    // LDS carve (all dynamic, 16-byte aligned pieces)
-    float* Vbuf = reinterpret_cast<float*>(smem);                 // [2][32*32]
-    float* Lc = Vbuf + 2048;                                      // [32*32] column-major diag block
-    float* red = Lc + 1024;                                       // [W][64][2]
-    float* stage = red + W * 128;                                 // [W][16*64] per-lane staging strips
-    double* etab = reinterpret_cast<double*>(stage + W * 1024);   // [N][8] (optional)
+    // LDS carve (all dynamic, 16-byte aligned pieces).  Region U is time-shared: stage 1/2 keep the
+    // per-lane staging strips and the exp table there, stage 3 the V ring and the diagonal-block ring.
+    float* red = reinterpret_cast<float*>(smem);                  // [W][64][2]
+    lds_flag_ptr flags = (lds_flag_ptr)(red + W * 128);           // [0] = pub, [1..W] = done[w]; 32 ints reserved
+    float* s_alpha = red + W * 128 + 32;                          // [ld]
+    int* s_ri = reinterpret_cast<int*>(s_alpha + ld);             // [ld]
+    float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);          // [N]   (ld is a multiple of 32 -> 16-B aligned)
+    float* U = reinterpret_cast<float*>(s_x4 + N);
+    float* stage = U;                                             // stage 2: [W][16*64] per-lane staging strips
+    double* etab = reinterpret_cast<double*>(U + W * 1024);       // stage 1/2: [N][8] exp table (optional)
+    float* Vbuf = U;                                              // stage 3: [RING][32*32] published V blocks
+    float* Lcr = U + RING * 1024;                                 // stage 3: [RING][32*32] diagonal blocks (column-major)
 
     const float a = (float)(sqrt(3.0) / (double)m.scale);
-    const float4* x4 = reinterpret_cast<const float4*>(m.x4);
 
     // this lane's column: query slot qi, component cq
     const int qi = l31 >> 2, cq = l31 & 3;
@@ -92,8 +112,23 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
     float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qi < jcnt) xq = A.xq[A.job_q[joff + qi]];
 
+    if (tid < 32) flags[tid] = -1;
+    {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
+        gfptr g_alpha = (gfptr)m.alpha;
+        giptr g_ri = (giptr)m.rowinfo;
+        gfptr g_x4 = (gfptr)m.x4;
+        if (!(A.dbg & 64)) for (int i = tid; i < ld; i += 64 * W) { s_alpha[i] = g_alpha[i]; s_ri[i] = g_ri[i]; }
+        if (!(A.dbg & 64)) for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
+        __syncthreads();
+    }
+    const float4* x4 = s_x4;
+    gfptr Lg = (gfptr)m.L;
+    // L through a buffer resource: one VGPR byte offset per lane + scalar offsets (no 64-bit VGPR addresses)
+    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.L, 0, (unsigned)ld * (unsigned)ld * 4u, 0x00020000);
+    const int Lvoff = (h * ld + l31) * 4;   // lane part of every L tile access: row l31 of the tile, column h
+
     // ---- stage 1: exp table, one entry per (training point, query slot) ----
-    if (A.use_table) {
+    if (A.use_table && !(A.dbg & 8)) {
         for (int idx = tid; idx < N * 8; idx += 64 * W) {
             int p = idx >> 3, s = idx & 7;
             double e = 0.0;
@@ -106,8 +141,8 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
             }
             etab[idx] = e;
         }
-        __syncthreads();
     }
+    __syncthreads();
 
     // ---- stage 2: B tiles into accumulators + partial means ----
     // Entries are produced by a compact runtime loop into a per-lane LDS strip and
@@ -118,13 +153,13 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
 #pragma unroll
     for (int t = 0; t < NBW; ++t) {
         const int b = wave + W * t;
-        if (b < nb) {
-#pragma unroll 1
+        if (b < nb && !(A.dbg & 1)) {
+#pragma unroll 2
             for (int r = 0; r < 16; ++r) {
                 float v = 0.f;
                 const int row = b * 32 + rowmap_t(r, h);
                 if (qact && row < K) {
-                    const int info = m.rowinfo[row];
+                    const int info = s_ri[row];
                     const int p = info & 0x0FFFFFFF, cr = (info >> 28) & 0xF;
                     float4 xp = x4[p];
                     float d[3] = {xp.x - xq.x, xp.y - xq.y, xp.z - xq.z};
@@ -142,7 +177,7 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
                             v = d_kf2(rr, dlo, dhi, lo == hi ? 1.0f : 0.0f, a, e);
                         }
                     }
-                    mp = fmaf(v, m.alpha[row], mp);
+                    mp = fmaf(v, s_alpha[row], mp);
                 }
                 strip[r * 64] = v;
             }
@@ -156,50 +191,103 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
     }
 
     // ---- stage 3: blocked forward substitution ----
+    __syncthreads();  // staging strips alias the rings
+    // Dataflow synchronisation instead of a barrier per step: `pub` = last published block,
+    // done[w] = last step whose updates wave w finished.  The owner of block c+1 updates that
+    // tile first, solves it and publishes V_{c+1} while the other waves are still busy with
+    // step c, so the diagonal solves of consecutive steps overlap with MFMA work of other waves.
     float ss = 0.f;  // partial sum of squares of V over this lane's rows
+    lds_flag_ptr pub = flags;
+    lds_flag_ptr done = flags + 1;
+    auto load_diag = [&](int c) {
+        if (A.dbg & 128) return;
+        float* Lc = Lcr + (c % RING) * 1024;
+        const int sbase = (c * 32 * ld + c * 32) * 4;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            Lc[(2 * cc + h) * 32 + l31] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, sbase + 2 * cc * ld * 4, 0));
+    };
+    auto solve_publish = [&](f32x16& v, int c) {
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (!(A.dbg & 2)) diag_solve32(v, Lcr + (c % RING) * 1024, h);
+        // ring slot free once every wave has finished step c - RING
+        if (c >= RING) {
 #pragma unroll 1
-    for (int c = 0; c < nb; ++c) {
-        const int wc = c % W, tc = c / W;
-        float* Vb = Vbuf + (c & 1) * 1024;
-        if (wave == wc) {
-            // diagonal block -> LDS (column-major), coalesced by column
-            const float* Ld = m.L + (size_t)(c * 32 + l31) + (size_t)(c * 32) * ld;
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) Lc[(2 * cc + h) * 32 + l31] = Ld[(size_t)(2 * cc + h) * ld];
-            float v[16];
-#pragma unroll
-            for (int t = 0; t < NBW; ++t)
-                if (t == tc) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[t][r];
-                }
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            diag_solve32(v, Lc, h, l31);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = rowmap_t(r, h);
-                Vb[rw * 32 + l31] = v[r];
-                if (c * 32 + rw < K) ss = fmaf(v[r], v[r], ss);
-            }
+            for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
+        float* Vw = Vbuf + (c % RING) * 1024;
 #pragma unroll
-        for (int t = 0; t < NBW; ++t) {
-            const int b = wave + W * t;
-            if (b > c && b < nb) {
-                const float* Lp = m.L + (size_t)(b * 32 + l31) + (size_t)(c * 32 + h) * ld;
-                float av[16];
+        for (int r = 0; r < 16; ++r) {
+            const int rw = rowmap_t(r, h);
+            Vw[rw * 32 + l31] = v[r];
+            if (c * 32 + rw < K) ss = fmaf(v[r], v[r], ss);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *pub = c;
+    };
+    auto update_tile = [&](f32x16& a_, const float* Vb, const float (&av)[16]) {
+        if (A.dbg & 4) return;
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) av[kk] = Lp[(size_t)(2 * kk) * ld];
+        for (int kk = 0; kk < 16; ++kk)
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[kk], Vb[(2 * kk + h) * 32 + l31], a_, 0, 0, 0);
+    };
+    auto load_a = [&](float (&av)[16], int b, int c) {
+        const int sbase = (c * 32 * ld + b * 32) * 4;
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[kk], Vb[(2 * kk + h) * 32 + l31], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+        for (int kk = 0; kk < 16; ++kk)
+            av[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, sbase + 2 * kk * ld * 4, 0));
+    };
+
+    if (wave == 0 && !(A.dbg & 32)) {  // block 0 has no dependency
+        load_diag(0);
+        solve_publish(acc[0], 0);
+    }
+    // Steps c = tc*W + wc.  Block c+1 belongs to wave (wc+1) mod W; its tile index is tc (same
+    // group) or tc+1 (wave 0 at the group boundary): static after unrolling tc, so the solve
+    // works in place on the accumulator registers.
+#pragma clang loop unroll(full)
+    for (int tc = 0; tc < NBW; ++tc) {
+#pragma unroll 1
+        for (int wc = 0; wc < W; ++wc) {
+            const int c = tc * W + wc;
+            if (c >= nb || (A.dbg & 32)) break;
+            const bool has_next = (c + 1 < nb);
+            const bool own_same = has_next && (wc + 1 < W) && (wave == wc + 1);
+            const bool own_next = has_next && (wc + 1 == W) && (wave == 0) && (tc + 1 < NBW);
+            float av[16];
+            if (own_same || own_next) { load_diag(c + 1); load_a(av, c + 1, c); }   // issue before waiting
+            while (*pub < c) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const float* Vb = Vbuf + (c % RING) * 1024;
+            if (own_same) {
+                update_tile(acc[tc], Vb, av);
+                solve_publish(acc[tc], c + 1);
             }
+            if (tc + 1 < NBW) {
+                if (own_next) {
+                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, av);
+                    solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
+            {
+                float avp[2][16];
+                auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
+                if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
+#pragma unroll
+                for (int t = tc; t < NBW; ++t) {
+                    if (t + 1 < NBW) { if (active(t + 1)) load_a(avp[(t + 1) & 1], wave + W * (t + 1), c); }
+                    if (active(t)) update_tile(acc[t], Vb, avp[t & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) done[wave] = c;
         }
     }
+    __syncthreads();
 
     // ---- stage 4: reduce partials (lane halves, then waves in fixed order) ----
     mp = mp + __shfl_xor(mp, 32);
@@ -221,34 +309,52 @@ __global__ __launch_bounds__(64 * W, (W <= 4 ? 2 : 1)) void ongpis_eval_kernel(E
     }
 }
 
-static size_t eval_lds_bytes(int W, int maxN, int use_table) {
-    return sizeof(float) * (2048 + 1024 + W * 128 + W * 1024) + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
+static const int kClassW[6] = {1, 2, 4, 4, 8, 8};
+static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
+
+static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
+    size_t fixed = sizeof(float) * (W * 128 + 32) + sizeof(float) * 2 * (size_t)maxLd + 16 * (size_t)maxN;
+    size_t s2 = sizeof(float) * (size_t)W * 1024 + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
+    size_t s3 = sizeof(float) * 2 * 4 * 1024;   // RING = 4
+    return fixed + std::max(s2, s3);
 }
 
-// wclass: 0 -> nb <= 8 (1 wave), 1 -> nb <= 32 (4 waves), 2 -> nb <= 64 (8 waves), 3 -> nb <= 96 (16 waves)
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in, hipStream_t s) {
     if (ntiles <= 0) return GPIS_OK;
+    if (wclass < 0 || wclass >= ONGPIS_NCLASS) return GPIS_ERR_ARG;
     EvalArgs args = args_in;
-    const int Ws[4] = {1, 4, 8, 8};
-    int W = Ws[wclass];
-    args.use_table = 1;
-    size_t lds = eval_lds_bytes(W, maxN, 1);
-    if (lds > 96 * 1024) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, 0); }
+    const int W = kClassW[wclass];
+    const int maxLd = kClassNb[wclass] * 32 + 32;
+    const size_t budget = 150 * 1024;     // one workgroup must fit; two per CU when <= 80 KB
+    args.use_table = 1; args.lds_model = 1;
+    { const char* e = getenv("GPIS_K4_DBG"); args.dbg = e ? atoi(e) : 0; }
+    size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
+    if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
+    if (lds > budget) return GPIS_ERR_LIMIT;
+    static bool attr_set = false;
+    if (!attr_set) {
+        attr_set = true;
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     switch (wclass) {
-        case 0: hipLaunchKernelGGL((ongpis_eval_kernel<1, 8>), dim3(ntiles), dim3(64), lds, s, args); break;
-        case 1: hipLaunchKernelGGL((ongpis_eval_kernel<4, 8>), dim3(ntiles), dim3(256), lds, s, args); break;
-        case 2: hipLaunchKernelGGL((ongpis_eval_kernel<8, 8>), dim3(ntiles), dim3(512), lds, s, args); break;
-        case 3: hipLaunchKernelGGL((ongpis_eval_kernel<8, 12>), dim3(ntiles), dim3(512), lds, s, args); break;
+        case 0: hipLaunchKernelGGL((ongpis_eval_kernel<1, 4, 2>), dim3(ntiles), dim3(64), lds, s, args); break;
+        case 1: hipLaunchKernelGGL((ongpis_eval_kernel<2, 4, 2>), dim3(ntiles), dim3(128), lds, s, args); break;
+        case 2: hipLaunchKernelGGL((ongpis_eval_kernel<4, 4, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
+        case 3: hipLaunchKernelGGL((ongpis_eval_kernel<4, 8, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
+        case 4: hipLaunchKernelGGL((ongpis_eval_kernel<8, 8, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
+        case 5: hipLaunchKernelGGL((ongpis_eval_kernel<8, 12, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
         default: return GPIS_ERR_ARG;
     }
     return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
 }
 
 int ongpis_eval_class(int nb) {
-    if (nb <= 8) return 0;
-    if (nb <= 32) return 1;
-    if (nb <= 64) return 2;
-    if (nb <= 96) return 3;
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) if (nb <= kClassNb[c]) return c;
     return -1;
 }
 

@@ -419,17 +419,17 @@ struct OnGPIS {
     // with packet-wise interleaved partial sums (order unspecified); this restatement fixes
     // 2*W interleaved partial chains: row r goes to chain (w, h) with w = (r / 32) mod W,
     // h = (r / 4) mod 2, each chain is an ascending fmaf chain, the pair (w,0)+(w,1) is added,
-    // and the W pair sums are accumulated in ascending w.  W = 1, 4, 8 for K <= 256, <= 1024,
-    // larger.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
+    // and the W pair sums are accumulated in ascending w.  W = 1, 2, 4, 8 for K <= 128, 256, 1024
+    // and above.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
     static int chains_W(int K) {
         int nb = (K + 31) / 32;
-        return nb <= 8 ? 1 : (nb <= 32 ? 4 : 8);
+        return nb <= 4 ? 1 : (nb <= 8 ? 2 : (nb <= 32 ? 4 : 8));
     }
     template <class F>
     static float reduce_O3(int K, F&& term_chain) {
         const int W = chains_W(K);
-        float P[8][2];
-        for (int w = 0; w < 8; ++w) P[w][0] = P[w][1] = 0.f;
+        float P[16][2];
+        for (int w = 0; w < 16; ++w) P[w][0] = P[w][1] = 0.f;
         for (int r = 0; r < K; ++r) {
             int w = (r >> 5) % W, h = (r >> 2) & 1;
             P[w][h] = term_chain(r, P[w][h]);
