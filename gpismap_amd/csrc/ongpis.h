@@ -20,6 +20,7 @@ struct ClusterModel {
     int nb;     // ceil(K / 32)
     float scale;            // GP length scale
     float* L;               // [ld*ld] lower Cholesky factor
+    float* Lt;              // [nb(nb+1)/2][1024] the same factor as 32x32 tiles in MFMA A-operand order (K4)
     float* alpha;           // [ld]
     float* x4;              // [N][4]  (x, y, z|0, 0)
     int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)
@@ -93,6 +94,7 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
+void ongpis_launch_tile(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;
@@ -105,6 +107,8 @@ struct EvalArgs {
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
     int use_table;           // exp table in LDS (else recompute per entry)
     int lds_model;           // alpha / rowinfo / x4 staged in LDS (set by ongpis_eval_launch)
+    unsigned long long* trace;  // optional per-wave cycle trace of workgroup `trace_block` (env GPIS_K4_TRACE)
+    int trace_block;
     int dbg;                 // timing ablations (env GPIS_K4_DBG; results are wrong when non-zero)
 };
 // K4 size classes by nb = ceil(K/32): 0: nb<=4 (1 wave x 4 tiles), 1: <=8 (2x4), 2: <=16 (4x4),

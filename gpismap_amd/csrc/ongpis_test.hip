@@ -49,12 +49,13 @@ __device__ __forceinline__ void diag_load(DiagCol& c, const float* Lc, int i, in
         if (8 * g + 7 > i) c.g[g] = p[2 * g];  // compile-time prune (i is a constant after unrolling)
     c.d = Lc[i * 32 + i];
 }
+template <bool PIPE>
 __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) {
     DiagCol cur, nxt;
     diag_load(cur, Lc, 0, h);
 #pragma unroll
     for (int i = 0; i < 32; ++i) {
-        if (i + 1 < 32) diag_load(nxt, Lc, i + 1, h);
+        if (PIPE && i + 1 < 32) diag_load(nxt, Lc, i + 1, h);
         const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
         float cand = v[ri] / cur.d;
         // broadcast row i from the half that owns it: v_permlane32_swap gives {low-half copy, high-half copy}
@@ -73,7 +74,8 @@ __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) 
                 v[r] = (row > i) ? upd : v[r];
             }
         }
-        cur = nxt;
+        if (PIPE) cur = nxt;
+        else if (i + 1 < 32) diag_load(cur, Lc, i + 1, h);
         __builtin_amdgcn_sched_barrier(0);
     }
 }
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     int* s_ri = reinterpret_cast<int*>(s_alpha + ld);             // [ld]
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);          // [N]   (ld is a multiple of 32 -> 16-B aligned)
     float* U = reinterpret_cast<float*>(s_x4 + N);
-    float* stage = U;                                             // stage 2: [W][16*64] per-lane staging strips
-    double* etab = reinterpret_cast<double*>(U + W * 1024);       // stage 1/2: [N][8] exp table (optional)
+    float* stage = U;                                             // stage 2: [W][32*36] per-wave padded tile
+    double* etab = reinterpret_cast<double*>(U + W * 1152);       // stage 1/2: [N][8] exp table (optional)
     float* Vbuf = U;                                              // stage 3: [RING][32*32] published V blocks
     float* Lcr = U + RING * 1024;                                 // stage 3: [RING][32*32] diagonal blocks (column-major)
 
@@ -112,7 +114,15 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
     if (qi < jcnt) xq = A.xq[A.job_q[joff + qi]];
 
+    // optional cycle trace of one workgroup (A.trace != nullptr): [wave][slot] timestamps
+    unsigned long long* trc = (A.trace && blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
+    int tri = 0;
+#define TRACE() do { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } while (0)
+    TRACE();
     if (tid < 32) flags[tid] = -1;
+    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
+        for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
         gfptr g_alpha = (gfptr)m.alpha;
         giptr g_ri = (giptr)m.rowinfo;
@@ -125,8 +135,13 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     gfptr Lg = (gfptr)m.L;
     // L through a buffer resource: one VGPR byte offset per lane + scalar offsets (no 64-bit VGPR addresses)
     const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.L, 0, (unsigned)ld * (unsigned)ld * 4u, 0x00020000);
-    const int Lvoff = (h * ld + l31) * 4;   // lane part of every L tile access: row l31 of the tile, column h
+    const int Lvoff = (h * ld + l31) * 4;   // lane part of a column-major L tile access: row l31 of the tile, column h
+    // off-diagonal tiles come from the re-tiled copy Lt (MFMA A-operand order): 4 x 16-byte loads per tile
+    const int ntl = nb * (nb + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const int Tvoff = lane * 16;
 
+    TRACE();
     // ---- stage 1: exp table, one entry per (training point, query slot) ----
     if (A.use_table && !(A.dbg & 8)) {
         for (int idx = tid; idx < N * 8; idx += 64 * W) {
@@ -144,52 +159,80 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     }
     __syncthreads();
 
+    TRACE();
     // ---- stage 2: B tiles into accumulators + partial means ----
-    // Entries are produced by a compact runtime loop into a per-lane LDS strip and
-    // then moved to the (statically indexed) accumulator registers.
+    // Cooperative generation: lane (r, qh) produces the 16 entries of tile row r for the queries
+    // 4qh..4qh+3 (distance, exp-table lookup and coefficient set-up shared by the 4 components),
+    // writes them to a padded per-wave LDS tile, which is then read back in MFMA C/D layout.
     f32x16 acc[NBW];
-    float mp = 0.f;  // partial k*^T alpha over this lane's rows
-    float* strip = stage + wave * 1024 + lane;  // strip[r*64]
+    float mp = 0.f;  // partial k*^T alpha over this lane's rows (order O3)
+    float* tbuf = stage + wave * (32 * 36);   // [32 rows][36] (stride 36 floats: conflict-free 16-byte writes)
+    {
+        const int rr_ = lane & 31, qh = lane >> 5;
+        float4 xqs[4];
 #pragma unroll
-    for (int t = 0; t < NBW; ++t) {
-        const int b = wave + W * t;
-        if (b < nb && !(A.dbg & 1)) {
-#pragma unroll 2
-            for (int r = 0; r < 16; ++r) {
-                float v = 0.f;
-                const int row = b * 32 + rowmap_t(r, h);
-                if (qact && row < K) {
+        for (int j = 0; j < 4; ++j) {
+            const int q = 4 * qh + j;
+            xqs[j] = (q < jcnt) ? A.xq[A.job_q[joff + q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int t = 0; t < NBW; ++t) {
+            const int b = wave + W * t;
+            if (b < nb && !(A.dbg & 1)) {
+                const int row = b * 32 + rr_;
+                float4 out[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < K) {
                     const int info = s_ri[row];
                     const int p = info & 0x0FFFFFFF, cr = (info >> 28) & 0xF;
-                    float4 xp = x4[p];
-                    float d[3] = {xp.x - xq.x, xp.y - xq.y, xp.z - xq.z};
-                    float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
-                    double e = A.use_table ? etab[p * 8 + qi] : exp((double)(-a * rr));
-                    if (cr == 0) {
-                        v = (cq == 0) ? d_kf(rr, a, e) : d_kf1(cq == 1 ? d[0] : (cq == 2 ? d[1] : d[2]), a, e);
-                    } else {
-                        float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
-                        if (cq == 0) v = -d_kf1(dr, a, e);
-                        else {
-                            int lo = min(cr, cq), hi = max(cr, cq);
-                            float dlo = lo == 1 ? d[0] : (lo == 2 ? d[1] : d[2]);
-                            float dhi = hi == 1 ? d[0] : (hi == 2 ? d[1] : d[2]);
-                            v = d_kf2(rr, dlo, dhi, lo == hi ? 1.0f : 0.0f, a, e);
+                    const float4 xp = x4[p];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int q = 4 * qh + j;
+                        if (q < jcnt) {
+                            float d[3] = {xp.x - xqs[j].x, xp.y - xqs[j].y, xp.z - xqs[j].z};
+                            float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
+                            double e = A.use_table ? etab[p * 8 + q] : exp((double)(-a * rr));
+                            float v0, v1, v2, v3;
+                            if (cr == 0) {
+                                v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
+                            } else {
+                                const float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
+                                v0 = -d_kf1(dr, a, e);
+                                // mixed second derivatives: lower component first (covFnc.cpp:300-308)
+                                v1 = (cr == 1) ? d_kf2(rr, d[0], d[0], 1.0f, a, e) : d_kf2(rr, d[0], dr, 0.0f, a, e);
+                                v2 = (cr == 2) ? d_kf2(rr, d[1], d[1], 1.0f, a, e)
+                                               : (cr == 1 ? d_kf2(rr, d[0], d[1], 0.0f, a, e) : d_kf2(rr, d[1], d[2], 0.0f, a, e));
+                                v3 = (cr == 3) ? d_kf2(rr, d[2], d[2], 1.0f, a, e) : d_kf2(rr, dr, d[2], 0.0f, a, e);
+                            }
+                            if (dim == 2) v3 = 0.f;
+                            out[j] = make_float4(v0, v1, v2, v3);
                         }
                     }
-                    mp = fmaf(v, s_alpha[row], mp);
                 }
-                strip[r * 64] = v;
+                float4* trow = reinterpret_cast<float4*>(tbuf + rr_ * 36 + 16 * qh);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) trow[j] = out[j];
+                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rw = rowmap_t(r, h);
+                    const float v = tbuf[rw * 36 + l31];
+                    acc[t][r] = v;
+                    if (b * 32 + rw < K) mp = fmaf(v, s_alpha[b * 32 + rw], mp);
+                }
+                __builtin_amdgcn_wave_barrier();
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = strip[r * 64];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
     }
 
+    TRACE();
     // ---- stage 3: blocked forward substitution ----
     __syncthreads();  // staging strips alias the rings
     // Dataflow synchronisation instead of a barrier per step: `pub` = last published block,
@@ -210,9 +253,9 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     auto solve_publish = [&](f32x16& v, int c) {
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        if (!(A.dbg & 2)) diag_solve32(v, Lcr + (c % RING) * 1024, h);
+        if (!(A.dbg & 2)) diag_solve32<(NBW <= 4)>(v, Lcr + (c % RING) * 1024, h);
         // ring slot free once every wave has finished step c - RING
-        if (c >= RING) {
+        if (c >= RING && !(A.dbg & 256)) {
 #pragma unroll 1
             for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
         }
@@ -233,10 +276,18 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[kk], Vb[(2 * kk + h) * 32 + l31], a_, 0, 0, 0);
     };
     auto load_a = [&](float (&av)[16], int b, int c) {
-        const int sbase = (c * 32 * ld + b * 32) * 4;
+        if (A.dbg & 16) {
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-            av[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, sbase + 2 * kk * ld * 4, 0));
+            for (int kk = 0; kk < 16; ++kk) av[kk] = 1.f;
+            return;
+        }
+        const int sbase = (b * (b + 1) / 2 + c) * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + g * 1024, 0);
+            av[4 * g + 0] = __uint_as_float(q[0]); av[4 * g + 1] = __uint_as_float(q[1]);
+            av[4 * g + 2] = __uint_as_float(q[2]); av[4 * g + 3] = __uint_as_float(q[3]);
+        }
     };
 
     if (wave == 0 && !(A.dbg & 32)) {  // block 0 has no dependency
@@ -255,25 +306,27 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             const bool has_next = (c + 1 < nb);
             const bool own_same = has_next && (wc + 1 < W) && (wave == wc + 1);
             const bool own_next = has_next && (wc + 1 == W) && (wave == 0) && (tc + 1 < NBW);
-            float av[16];
-            if (own_same || own_next) { load_diag(c + 1); load_a(av, c + 1, c); }   // issue before waiting
-            while (*pub < c) __builtin_amdgcn_s_sleep(1);
+            float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
+            if (own_same || own_next) { load_diag(c + 1); load_a(avp[0], c + 1, c); }   // issue before waiting
+            TRACE();
+            if (!(A.dbg & 256)) while (*pub < c) __builtin_amdgcn_s_sleep(1);
+            TRACE();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const float* Vb = Vbuf + (c % RING) * 1024;
             if (own_same) {
-                update_tile(acc[tc], Vb, av);
+                update_tile(acc[tc], Vb, avp[0]);
                 solve_publish(acc[tc], c + 1);
             }
             if (tc + 1 < NBW) {
                 if (own_next) {
-                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, av);
+                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, avp[0]);
                     solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
                 }
             }
+            TRACE();
             __builtin_amdgcn_sched_barrier(0);
             // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
             {
-                float avp[2][16];
                 auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
                 if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
 #pragma unroll
@@ -283,12 +336,15 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            TRACE();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) done[wave] = c;
         }
     }
     __syncthreads();
 
+    TRACE();
+    if (trc && lane == 0) trc[511] = tri;
     // ---- stage 4: reduce partials (lane halves, then waves in fixed order) ----
     mp = mp + __shfl_xor(mp, 32);
     ss = ss + __shfl_xor(ss, 32);
@@ -314,7 +370,7 @@ static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
 
 static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
     size_t fixed = sizeof(float) * (W * 128 + 32) + sizeof(float) * 2 * (size_t)maxLd + 16 * (size_t)maxN;
-    size_t s2 = sizeof(float) * (size_t)W * 1024 + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
+    size_t s2 = sizeof(float) * (size_t)W * 1152 + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
     size_t s3 = sizeof(float) * 2 * 4 * 1024;   // RING = 4
     return fixed + std::max(s2, s3);
 }
@@ -328,6 +384,13 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     const size_t budget = 150 * 1024;     // one workgroup must fit; two per CU when <= 80 KB
     args.use_table = 1; args.lds_model = 1;
     { const char* e = getenv("GPIS_K4_DBG"); args.dbg = e ? atoi(e) : 0; }
+    static unsigned long long* d_trace = nullptr;
+    args.trace = nullptr; args.trace_block = 0;
+    if (const char* e = getenv("GPIS_K4_TRACE")) {
+        if (!d_trace) { (void)hipMalloc(&d_trace, sizeof(unsigned long long) * 512 * 16); }
+        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 16, s);
+        args.trace = d_trace; args.trace_block = atoi(e);
+    }
     size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
     if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
     if (lds > budget) return GPIS_ERR_LIMIT;
@@ -349,6 +412,20 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
         case 4: hipLaunchKernelGGL((ongpis_eval_kernel<8, 8, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
         case 5: hipLaunchKernelGGL((ongpis_eval_kernel<8, 12, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
         default: return GPIS_ERR_ARG;
+    }
+    if (args.trace && wclass == 3) {
+        (void)hipStreamSynchronize(s);
+        static unsigned long long h[512 * 16];
+        (void)hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost);
+        FILE* f = fopen("gpurun_out/k4_trace.txt", "w");
+        if (f) {
+            for (int w = 0; w < W; ++w) {
+                int n = (int)h[w * 512 + 511];
+                fprintf(f, "wave %d n %d\n", w, n);
+                for (int i = 0; i < n && i < 511; ++i) fprintf(f, "%llu\n", h[w * 512 + i] - h[0]);
+            }
+            fclose(f);
+        }
     }
     return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
 }

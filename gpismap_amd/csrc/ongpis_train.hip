@@ -277,12 +277,47 @@ __global__ __launch_bounds__(1024) void ongpis_chol_kernel(const ClusterModel* _
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
 }
 
+// ---------------------------------------------------------------------------
+// Re-tile the factor for K4: block (b, c), b >= c, is stored as 1024 consecutive floats in the
+// order the MFMA A operand consumes it -- [g][lane][j] holds L[32b + (lane&31)][32c + 2(4g+j) + (lane>>5)]
+// -- so a lane fetches its 16 operands of a tile with four 16-byte loads.  grid = jobs, block = 256.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ongpis_tile_kernel(const ClusterModel* __restrict__ models,
+                                                          const int* __restrict__ d_jobs) {
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ClusterModel m = models[JOB_MODEL(job)];
+    const int nb = m.nb, ld = m.ld;
+    const int ntiles = nb * (nb + 1) / 2;
+    const int h = lane >> 5, l31 = lane & 31;
+    for (int t = wave; t < ntiles; t += 4) {
+        // t = b(b+1)/2 + c
+        int b = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
+        while ((b + 1) * (b + 2) / 2 <= t) ++b;
+        while (b * (b + 1) / 2 > t) --b;
+        int c = t - b * (b + 1) / 2;
+        const float* src = m.L + (size_t)(b * 32 + l31) + (size_t)(c * 32 + h) * ld;
+        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)t * 1024);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 q;
+            q.x = src[(size_t)(2 * (4 * g + 0)) * ld];
+            q.y = src[(size_t)(2 * (4 * g + 1)) * ld];
+            q.z = src[(size_t)(2 * (4 * g + 2)) * ld];
+            q.w = src[(size_t)(2 * (4 * g + 3)) * ld];
+            dst[g * 64 + lane] = q;
+        }
+    }
+}
+
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_gather_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs, d_ids, d_pts, pts_cap);
 }
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
+}
+void ongpis_launch_tile(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
+    hipLaunchKernelGGL(ongpis_tile_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs);
 }
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_chol_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
