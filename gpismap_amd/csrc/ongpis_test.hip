@@ -87,7 +87,10 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    // logical wave index = block-row ownership; optionally rotated for every other resident set so that
+    // two workgroups sharing a CU do not put the same role on the same SIMD at the same time
+    const int wave = ((tid >> 6) + (((A.dbg & 1024) && ((blockIdx.x >> 8) & 1)) ? (W + 1) / 2 : 0)) % W;
     const int h = lane >> 5, l31 = lane & 31;
     const ClusterModel m = A.models[A.tile_model[tile]];
     const int N = m.N, K = m.K, ld = m.ld, nb = m.nb, dim = m.dim;
@@ -120,8 +123,8 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #define TRACE() do { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
-    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
-        for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_sleep(127);
+    if ((A.dbg & 512) && blockIdx.x >= 256 && blockIdx.x < 512) {  // experiment: one-time stagger of the second resident set
+        for (int i = 0; i < 28; ++i) __builtin_amdgcn_s_sleep(127);
     }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
         gfptr g_alpha = (gfptr)m.alpha;

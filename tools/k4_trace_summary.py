@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/k4_trace.txt (GPIS_K4_TRACE=<block> tools/k4_bench.py ...)."""
+import sys
+lines = open(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/k4_trace.txt').read().split('\n')
+waves = {}; cur = None
+for l in lines:
+    if l.startswith('wave'):
+        cur = int(l.split()[1]); waves[cur] = []
+    elif l.strip():
+        waves[cur].append(int(l))
+for w, ts in waves.items():
+    print('wave', w, 'events', len(ts), 'total cycles', ts[-1] - ts[0])
+    print('  stage0 %d  exp %d  bgen %d' % (ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]))
+    steps = ts[4:-1] if (len(ts) - 5) % 4 == 0 else ts[4:]
+    n = len(steps) // 4
+    waitt = sum(steps[4 * i + 1] - steps[4 * i] for i in range(n)); own = sum(steps[4 * i + 2] - steps[4 * i + 1] for i in range(n))
+    gen = sum(steps[4 * i + 3] - steps[4 * i + 2] for i in range(n)); gap = sum(steps[4 * (i + 1)] - steps[4 * i + 3] for i in range(n - 1))
+    print('  steps %d: wait %d  owner(update+solve) %d  general updates %d  inter-step %d' % (n, waitt, own, gen, gap))
+    if w == 1 and len(sys.argv) > 2:
+        for i in range(n):
+            print('    c=%d wait %d owner %d general %d' % (i, steps[4 * i + 1] - steps[4 * i], steps[4 * i + 2] - steps[4 * i + 1], steps[4 * i + 3] - steps[4 * i + 2]))
