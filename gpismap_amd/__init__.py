@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpismap_amd.so")
+LIB_PATH = os.environ.get("GPISMAP_AMD_LIB", os.path.join(_HERE, "libgpismap_amd.so"))
 _lib = None
 
 fp = C.POINTER(C.c_float)

@@ -65,19 +65,18 @@ __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) 
         v[ri] = (h == hi_) ? vi : v[ri];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int row0 = (r & 3) + 8 * (r >> 2);   // row of register r in the low half; +4 in the high half
-            const float4 q = cur.g[r >> 2];
-            const float lri = (r & 3) == 0 ? q.x : ((r & 3) == 1 ? q.y : ((r & 3) == 2 ? q.z : q.w));
-            if (row0 > i) {
-                v[r] = fmaf(-lri, vi, v[r]);           // below row i in both halves: unconditional
-            } else if (row0 + 4 > i) {
-                float upd = fmaf(-lri, vi, v[r]);      // below row i only in the high half
-                v[r] = h ? upd : v[r];
+            const int row0 = (r & 3) + 8 * (r >> 2);
+            if (row0 + 4 > i) {
+                const int row = row0 + 4 * h;
+                const float4 q = cur.g[r >> 2];
+                float lri = (r & 3) == 0 ? q.x : ((r & 3) == 1 ? q.y : ((r & 3) == 2 ? q.z : q.w));
+                float upd = fmaf(-lri, vi, v[r]);
+                v[r] = (row > i) ? upd : v[r];
             }
         }
         if (PIPE) cur = nxt;
         else if (i + 1 < 32) diag_load(cur, Lc, i + 1, h);
-        if (i % 4 == 3) __builtin_amdgcn_sched_barrier(0);   // let the trailing fmas of a step overlap the next division
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
@@ -88,10 +87,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    // logical wave index = block-row ownership; optionally rotated for every other resident set so that
-    // two workgroups sharing a CU do not put the same role on the same SIMD at the same time
-    const int wave = ((tid >> 6) + (((A.dbg & 1024) && ((blockIdx.x >> 8) & 1)) ? (W + 1) / 2 : 0)) % W;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, l31 = lane & 31;
     const ClusterModel m = A.models[A.tile_model[tile]];
     const int N = m.N, K = m.K, ld = m.ld, nb = m.nb, dim = m.dim;
@@ -124,8 +120,8 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #define TRACE() do { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
-    if ((A.dbg & 512) && blockIdx.x >= 256 && blockIdx.x < 512) {  // experiment: one-time stagger of the second resident set
-        for (int i = 0; i < 28; ++i) __builtin_amdgcn_s_sleep(127);
+    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
+        for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_sleep(127);
     }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
         gfptr g_alpha = (gfptr)m.alpha;
@@ -255,18 +251,14 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             Lc[(2 * cc + h) * 32 + l31] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, sbase + 2 * cc * ld * 4, 0));
     };
     auto solve_publish = [&](f32x16& v, int c) {
-        if (A.dbg & 2048) TRACE();
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
-        if (A.dbg & 2048) TRACE();
-        if (!(A.dbg & 2)) diag_solve32<true>(v, Lcr + (c % RING) * 1024, h);
-        if (A.dbg & 2048) TRACE();
+        if (!(A.dbg & 2)) diag_solve32<(NBW <= 4)>(v, Lcr + (c % RING) * 1024, h);
         // ring slot free once every wave has finished step c - RING
         if (c >= RING && !(A.dbg & 256)) {
 #pragma unroll 1
             for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
         }
-        if (A.dbg & 2048) TRACE();
         float* Vw = Vbuf + (c % RING) * 1024;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -298,16 +290,13 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
         }
     };
 
-    // Ownership look-ahead: block n belongs to wave n mod W (tile index n / W).  Its diagonal block
-    // (LDS ring) and the A operands of its last update (registers, avo[]) are fetched one step before
-    // they are needed so that the publish chain never waits on memory.
-    float avo[16];
-    auto owns = [&](int n) { return n < nb && (n % W) == wave; };
     if (wave == 0 && !(A.dbg & 32)) {  // block 0 has no dependency
         load_diag(0);
         solve_publish(acc[0], 0);
     }
-    if (owns(1)) { load_diag(1); load_a(avo, 1, 0); }
+    // Steps c = tc*W + wc.  Block c+1 belongs to wave (wc+1) mod W; its tile index is tc (same
+    // group) or tc+1 (wave 0 at the group boundary): static after unrolling tc, so the solve
+    // works in place on the accumulator registers.
 #pragma clang loop unroll(full)
     for (int tc = 0; tc < NBW; ++tc) {
 #pragma unroll 1
@@ -317,27 +306,25 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             const bool has_next = (c + 1 < nb);
             const bool own_same = has_next && (wc + 1 < W) && (wave == wc + 1);
             const bool own_next = has_next && (wc + 1 == W) && (wave == 0) && (tc + 1 < NBW);
-            float avp[2][16];
+            float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
+            if (own_same || own_next) { load_diag(c + 1); load_a(avp[0], c + 1, c); }   // issue before waiting
             TRACE();
             if (!(A.dbg & 256)) while (*pub < c) __builtin_amdgcn_s_sleep(1);
             TRACE();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             const float* Vb = Vbuf + (c % RING) * 1024;
             if (own_same) {
-                update_tile(acc[tc], Vb, avo);
+                update_tile(acc[tc], Vb, avp[0]);
                 solve_publish(acc[tc], c + 1);
             }
             if (tc + 1 < NBW) {
                 if (own_next) {
-                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, avo);
+                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, avp[0]);
                     solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
                 }
             }
             TRACE();
             __builtin_amdgcn_sched_barrier(0);
-            // fetch for the block this wave publishes during the NEXT step (ring slot (c+2) % RING was last
-            // used by block c+2-RING, published long ago)
-            if (owns(c + 2)) { load_diag(c + 2); load_a(avo, c + 2, c + 1); }
             // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
             {
                 auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
@@ -407,7 +394,6 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
     if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
     if (lds > budget) return GPIS_ERR_LIMIT;
-    if (const char* e = getenv("GPIS_K4_LDSPAD")) lds = std::max(lds, (size_t)atoi(e) * 1024);   // experiment: limit workgroups per CU
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
@@ -416,20 +402,13 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
         (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
     switch (wclass) {
         case 0: hipLaunchKernelGGL((ongpis_eval_kernel<1, 4, 2>), dim3(ntiles), dim3(64), lds, s, args); break;
         case 1: hipLaunchKernelGGL((ongpis_eval_kernel<2, 4, 2>), dim3(ntiles), dim3(128), lds, s, args); break;
         case 2: hipLaunchKernelGGL((ongpis_eval_kernel<4, 4, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
-        case 3: {
-            const char* e = getenv("GPIS_K4_CFG");
-            int cfg = e ? atoi(e) : 0;
-            if (cfg == 1) hipLaunchKernelGGL((ongpis_eval_kernel<8, 4, 2>), dim3(ntiles), dim3(512), eval_lds_bytes(8, maxN, maxLd, args.use_table), s, args);
-            else hipLaunchKernelGGL((ongpis_eval_kernel<4, 8, 2>), dim3(ntiles), dim3(256), lds, s, args);
-            break;
-        }
+        case 3: hipLaunchKernelGGL((ongpis_eval_kernel<4, 8, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
         case 4: hipLaunchKernelGGL((ongpis_eval_kernel<8, 8, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
         case 5: hipLaunchKernelGGL((ongpis_eval_kernel<8, 12, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
         default: return GPIS_ERR_ARG;
