@@ -101,7 +101,8 @@ class GPisMap3:
 
     STAT_KEYS = ("obsgp_groups", "obsgp_queries", "clusters_trained", "late_reevals", "clusters",
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
-                 "last_train_ms", "model_bytes")
+                 "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
+                 "upd_gps_ms")
 
     def __init__(self, cam6=None):
         self.L = lib()
@@ -165,8 +166,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 12)()
-        _check(self.L.gpis3_stats(self.h, a, 12), "gpis3_stats")
+        a = (C.c_double * 17)()
+        _check(self.L.gpis3_stats(self.h, a, 17), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def set_profile(self, on=True):

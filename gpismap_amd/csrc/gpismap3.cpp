@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <chrono>
 #include <cstring>
 #include <functional>
 #include <unordered_map>
@@ -609,16 +610,28 @@ void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisM
     Impl& m = *p_;
     if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
     m.tree.recycle();
+    auto t0 = std::chrono::steady_clock::now();
+    auto lap = [&](int i) {
+        auto t1 = std::chrono::steady_clock::now();
+        m.last_update_ms[i] = std::chrono::duration<float, std::milli>(t1 - t0).count();
+        t0 = t1;
+    };
+    for (float& v : m.last_update_ms) v = 0.f;
     if (!m.preprocData(dataz, N, pose)) return;
+    lap(0);
     if (m.regressObs()) {
+        lap(1);
         m.updateMapPoints();
+        lap(2);
         if (!m.has_tree) {  // addNewMeas :571-578
             float c[3] = {0.f, 0.f, 0.f};
             m.tree.make_root(c);
             m.has_tree = true;
         }
         m.evalPoints();
+        lap(3);
         m.updateGPs();
+        lap(4);
     }
 }
 
@@ -674,11 +687,12 @@ void GPisMap3::getAllNodes(std::vector<float>& out) {
 // accessors used by the C-ABI (capi.cpp)
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
-    double v[12] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[17] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
-                    (double)m.store.last_train_ms, (double)m.stat_model_bytes};
-    for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
+                    (double)m.store.last_train_ms, (double)m.stat_model_bytes,
+                    m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4]};
+    for (int i = 0; i < n && i < 17; ++i) out[i] = v[i];
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();
