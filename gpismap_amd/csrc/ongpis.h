@@ -20,7 +20,7 @@ struct ClusterModel {
     int nb;     // ceil(K / 32)
     float scale;            // GP length scale
     float* L;               // [ld*ld] lower Cholesky factor
-    float* Lt;              // [nb(nb+1)/2][1024] the same factor as 32x32 tiles in MFMA A-operand order (K4)
+    float* Lt;              // [nbr(nbr+1)/2][1024], nbr = ld/32: the same factor as 32x32 tiles in MFMA A-operand order
     float* alpha;           // [ld]
     float* x4;              // [N][4]  (x, y, z|0, 0)
     int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)

@@ -59,7 +59,7 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     size_t oY = align_up(oR + szR, 256), szY = sizeof(float) * ld;
     size_t oS = align_up(oY + szY, 256), szS = sizeof(float) * 2 * (size_t)N;
     size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
-    int nbk = (K + 31) / 32;
+    int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     size_t oT = align_up(oG + szG, 256), szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
     size_t total = align_up(oT + szT, 256);
     if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
@@ -144,8 +144,7 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     }
     ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
     ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
-    ongpis_launch_chol(d_models_, d_jobs_, nj, s);
-    ongpis_launch_tile(d_models_, d_jobs_, nj, s);
+    ongpis_launch_chol(d_models_, d_jobs_, nj, s);   // also produces the re-tiled copy Lt
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));

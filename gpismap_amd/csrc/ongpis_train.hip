@@ -14,6 +14,7 @@
 //           v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain => same bits as the
 //           unblocked chain order), then blocked backward substitution for alpha.
 #include "ongpis.h"
+#include "tile_solve.h"
 
 namespace gpis {
 
@@ -149,113 +150,184 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 }
 
 // ---------------------------------------------------------------------------
-// K3.  grid = jobs, block = 1024 (16 waves).  Factorises rows 0..K (row K = y).
+// K3.  grid = jobs, block = 512 (8 waves), two workgroups per CU.
+// Left-looking 32-blocked Cholesky of rows 0..K (row K = y) with the tiles of the current block
+// column resident in MFMA accumulators:
+//   tile(bi, j) = A(bi, j) - sum_{p<j} L(bi, p) L(j, p)^T      v_mfma_f32_32x32x2_f32, ascending p and k
+//   diagonal tile: factorised in LDS by wave 0 (column steps, lane = row)
+//   other tiles:   X L_jj^T = T solved in registers with the same routine K4 uses (diag_solve32)
+// Operands come from the re-tiled copy Lt (MFMA A-operand order, 4 x 16-byte loads per tile), which is
+// produced on the fly together with the column-major factor.  No read-modify-write of the trailing
+// matrix through memory.  The per-element operation order is the ascending-k fmaf chain of
+// dev_common.h: results are bit-identical to the unblocked chain.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ int rowmap(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 + c; }
 
-__global__ __launch_bounds__(1024) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
-                                                           const int* __restrict__ d_jobs) {
-    __shared__ float D[32 * 33];
+template <int NT>
+__global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
+                                                              const int* __restrict__ d_jobs) {
+    __shared__ __attribute__((aligned(16))) float D[32 * 33];       // diagonal tile, row-major padded (factor workspace)
+    __shared__ __attribute__((aligned(16))) float Lc[32 * 32];      // factored diagonal tile, column-major (for the solves)
+    __shared__ __attribute__((aligned(16))) float Tt[8][32 * 36];   // per-wave tile transpose buffer
     __shared__ float av[32];
     const int job = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6, nwaves = 16;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, l31 = lane & 31;
+    constexpr int NW = 8;
     const ClusterModel m = models[JOB_MODEL(job)];
-    const int K = m.K, ld = m.ld;
+    const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
-    const int nrows = K + 1;
-    const int npan = (K + 31) / 32;
-    const int nbr = ld / 32;           // block rows (ld = 32*ceil((K+1)/32))
-    const int bjmax = (K - 1) / 32;    // last block column that holds real columns
+    const int nbr = ld / 32;           // block rows (ld = 32*ceil((K+1)/32)): includes the block holding row K
+    const int ntl = nbr * (nbr + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const int Tvoff = lane * 16;
 
-    for (int p = 0; p < npan; ++p) {
-        const int pr = 32 * p;
-        const int pw = min(32, K - pr);
-        // (a) diagonal block, wave 0, lane = row within block
-        if (wave == 0) {
-            if (lane < 32)
-                for (int c = 0; c < 32; ++c) D[lane * 33 + c] = L[(pr + lane) + (size_t)(pr + c) * ld];
-            __builtin_amdgcn_s_waitcnt(0);  // LDS writes of this wave done
-            for (int j = 0; j < pw; ++j) {
-                float d = sqrtf(D[j * 33 + j]);
-                float lij = 0.f;
-                bool below = (lane > j && lane < 32);
-                if (below) lij = D[lane * 33 + j] / d;
-                if (lane == j) D[j * 33 + j] = d;
-                if (below) D[lane * 33 + j] = lij;
-                if (below) {
-                    float nl = -lij;
-                    int kend = min(lane, pw - 1);
-                    for (int k = j + 1; k <= kend; ++k) D[lane * 33 + k] = fmaf(nl, D[k * 33 + j], D[lane * 33 + k]);
+    auto load_tile = [&](float (&o)[16], int b, int c) {   // Lt(b, c) in A-operand order
+        const int sbase = tri_index(b, c) * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + g * 1024, 0);
+            o[4 * g + 0] = __uint_as_float(q[0]); o[4 * g + 1] = __uint_as_float(q[1]);
+            o[4 * g + 2] = __uint_as_float(q[2]); o[4 * g + 3] = __uint_as_float(q[3]);
+        }
+    };
+
+    for (int j = 0; j < nb; ++j) {
+        const int pw = min(32, K - 32 * j);
+        for (int t0 = 0; j + wave + NW * t0 < nbr || (t0 == 0); t0 += NT) {
+            // ---- accumulate: acc[tt] = A(bi, j) - sum_p L(bi, p) L(j, p)^T (transposed: lane = row, regs = cols)
+            f32x16 acc[NT];
+            bool act[NT];
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt) {
+                const int bi = j + wave + NW * (t0 + tt);
+                act[tt] = bi < nbr;
+                if (act[tt]) {
+                    const float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = Cb[(size_t)rowmap_t(r, h) * ld];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
                 }
             }
-            if (lane < 32)
-                for (int c = 0; c < pw; ++c)
-                    if (c <= lane) L[(pr + lane) + (size_t)(pr + c) * ld] = D[lane * 33 + c];
-        }
-        __syncthreads();
-        // (b) panel solve: one thread per row below the diagonal block
-        for (int i = pr + 32 + tid; i < nrows; i += 1024) {
-            float x[32];
+            if (act[0]) {
+                float a_[2][16];
+                if (j > 0) load_tile(a_[0], j, 0);
+#pragma unroll 1
+                for (int p = 0; p < j; p += 2) {
+                    // two panels per iteration so the double buffer index stays static
+                    if (p + 1 < j) load_tile(a_[1], j, p + 1);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) x[c] = (c < pw) ? L[i + (size_t)(pr + c) * ld] : 0.f;
+                    for (int tt = 0; tt < NT; ++tt) {
+                        if (act[tt]) {
+                            float b_[16];
+                            load_tile(b_, j + wave + NW * (t0 + tt), p);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) {
-                if (c < pw) {
-                    float s = x[c];
+                            for (int kk = 0; kk < 16; ++kk)
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], b_[kk], acc[tt], 0, 0, 0);
+                        }
+                    }
+                    if (p + 1 < j) {
+                        if (p + 2 < j) load_tile(a_[0], j, p + 2);
 #pragma unroll
-                    for (int k = 0; k < c; ++k) s = fmaf(-x[k], D[c * 33 + k], s);
-                    x[c] = s / D[c * 33 + c];
+                        for (int tt = 0; tt < NT; ++tt) {
+                            if (act[tt]) {
+                                float b_[16];
+                                load_tile(b_, j + wave + NW * (t0 + tt), p + 1);
+#pragma unroll
+                                for (int kk = 0; kk < 16; ++kk)
+                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], b_[kk], acc[tt], 0, 0, 0);
+                            }
+                        }
+                    }
                 }
             }
+            // ---- diagonal tile: wave 0, first round
+            if (t0 == 0) {
+                if (wave == 0) {
 #pragma unroll
-            for (int c = 0; c < 32; ++c) if (c < pw) L[i + (size_t)(pr + c) * ld] = x[c];
-        }
-        __syncthreads();
-        // (c) trailing update, 32x32 tiles, computed transposed so that lanes map to
-        //     consecutive rows (coalesced C traffic): D'[i'][j'] = C[bi*32+j'][bj*32+i'].
-        if (pw == 32) {
-            int cntr = 0;
-            const int h = lane >> 5, l31 = lane & 31;
-            for (int bi = p + 1; bi < nbr; ++bi) {
-                int bje = min(bi, bjmax);
-                for (int bj = p + 1; bj <= bje; ++bj, ++cntr) {
-                    if ((cntr % nwaves) != wave) continue;
-                    f32x16 acc;
-                    float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(bj * 32) * ld;
+                    for (int r = 0; r < 16; ++r) D[l31 * 33 + rowmap_t(r, h)] = acc[0][r];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                    volatile float* Dv = D;
+                    for (int c = 0; c < pw; ++c) {
+                        float d = sqrtf(Dv[c * 33 + c]);
+                        float lij = 0.f;
+                        const bool below = (lane > c && lane < 32);
+                        if (below) lij = Dv[lane * 33 + c] / d;
+                        if (lane == c) Dv[c * 33 + c] = d;
+                        if (below) Dv[lane * 33 + c] = lij;
+                        if (below) {
+                            const float nl = -lij;
+                            const int kend = min(lane, pw - 1);
+                            for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    // column-major copy for the solves, and the factor itself to global memory (lower part)
+                    if (lane < 32) {
+                        for (int c = 0; c < 32; ++c) {
+                            float v = Dv[lane * 33 + c];
+                            Lc[c * 32 + lane] = v;
+                            if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            // ---- other tiles: X = T L_jj^{-T}, then store column-major and re-tiled
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = Cb[(size_t)rowmap(r, h) * ld];
-                    const float* Pa = L + (size_t)(bj * 32 + l31) + (size_t)(pr + h) * ld;
-                    const float* Pb = L + (size_t)(bi * 32 + l31) + (size_t)(pr + h) * ld;
-                    float av_[16], bv_[16];
+            for (int tt = 0; tt < NT; ++tt) {
+                const int bi = j + wave + NW * (t0 + tt);
+                if (act[tt] && bi != j) {
+                    diag_solve32<true>(acc[tt], Lc, h);
+                    float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) { av_[kk] = Pa[(size_t)(2 * kk) * ld]; bv_[kk] = Pb[(size_t)(2 * kk) * ld]; }
+                    for (int r = 0; r < 16; ++r) Cb[(size_t)rowmap_t(r, h) * ld] = acc[tt][r];
+                    {
+                        float* T = Tt[wave];
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-av_[kk], bv_[kk], acc, 0, 0, 0);
+                        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = acc[tt][r];
+                        __builtin_amdgcn_s_waitcnt(0xc07f);
+                        __builtin_amdgcn_wave_barrier();
+                        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Cb[(size_t)rowmap(r, h) * ld] = acc[r];
+                        for (int g = 0; g < 4; ++g) {
+                            float4 q;
+                            q.x = T[l31 * 36 + 2 * (4 * g + 0) + h];
+                            q.y = T[l31 * 36 + 2 * (4 * g + 1) + h];
+                            q.z = T[l31 * 36 + 2 * (4 * g + 2) + h];
+                            q.w = T[l31 * 36 + 2 * (4 * g + 3) + h];
+                            dst[g * 64 + lane] = q;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
                 }
             }
+            if (j + wave + NW * (t0 + NT) >= nbr && t0 > 0) { /* loop condition handles exit */ }
         }
-        __syncthreads();
+        __syncthreads();   // column j complete: Lt tiles visible, Lc reusable
     }
 
     // z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2)
-    for (int j = tid; j < K; j += 1024) m.y[j] = L[K + (size_t)j * ld];
+    for (int jj = tid; jj < K; jj += 512) m.y[jj] = L[K + (size_t)jj * ld];
     __syncthreads();
-    const int nb = m.nb;
     for (int c = nb - 1; c >= 0; --c) {
         const int cr = 32 * c;
         if (wave == 0) {
             if (lane < 32)
                 for (int cc = 0; cc < 32; ++cc) D[lane * 33 + cc] = L[(cr + lane) + (size_t)(cr + cc) * ld];
             __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            volatile float* Dv = D;
             float b = (lane < 32 && cr + lane < K) ? m.y[cr + lane] : 0.f;
             for (int k = 31; k >= 0; --k) {
                 if (cr + k >= K) continue;
-                float t = b / D[(lane & 31) * 33 + (lane & 31)];
+                float t = b / Dv[(lane & 31) * 33 + (lane & 31)];
                 float ak = __shfl(t, k);
                 if (lane == k) b = ak;
-                if (lane < k) b = fmaf(-D[k * 33 + lane], ak, b);
+                if (lane < k) b = fmaf(-Dv[k * 33 + lane], ak, b);
             }
             if (lane < 32) {
                 av[lane] = (cr + lane < K) ? b : 0.f;
@@ -263,17 +335,17 @@ __global__ __launch_bounds__(1024) void ongpis_chol_kernel(const ClusterModel* _
             }
         }
         __syncthreads();
-        for (int j = tid; j < cr; j += 1024) {
-            float s = m.y[j];
-            const float* col = L + (size_t)cr + (size_t)j * ld;
+        for (int jj = tid; jj < cr; jj += 512) {
+            float s = m.y[jj];
+            const float* col = L + (size_t)cr + (size_t)jj * ld;
             for (int k = 31; k >= 0; --k)
                 if (cr + k < K) s = fmaf(-col[k], av[k], s);
-            m.y[j] = s;
+            m.y[jj] = s;
         }
         __syncthreads();
     }
     // restore the identity in row K so the padded square is a valid triangular factor
-    for (int j = tid; j < K; j += 1024) L[K + (size_t)j * ld] = 0.f;
+    for (int jj = tid; jj < K; jj += 512) L[K + (size_t)jj * ld] = 0.f;
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
 }
 
@@ -320,7 +392,7 @@ void ongpis_launch_tile(const ClusterModel* d_models, const int* d_jobs, int njo
     hipLaunchKernelGGL(ongpis_tile_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs);
 }
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
-    hipLaunchKernelGGL(ongpis_chol_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
+    hipLaunchKernelGGL((ongpis_chol_kernel<3>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
 }  // namespace gpis

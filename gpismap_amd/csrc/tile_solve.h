@@ -1,0 +1,57 @@
+// Shared device helpers for 32x32 tiles held in MFMA C/D layout (v_mfma_f32_32x32x2_f32):
+// lane l owns column (l & 31) and the 16 rows rowmap(r, l >> 5), r = 0..15.
+#pragma once
+#include "dev_common.h"
+
+namespace gpis {
+
+__device__ __forceinline__ int rowmap_t(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// In-register solve of the 32x32 lower-triangular system for the 32 columns of a
+// tile held in MFMA C/D layout (lane = column, 16 of the 32 rows per lane half).
+// Lc = diagonal block of L, column-major in LDS.  Row i is finalised by the half
+// that owns it (true division), broadcast to the partner half, then every later
+// row gets one fmaf: ascending chain, identical to the unblocked order.
+// Column i of the block is fetched as four 16-byte LDS reads per lane half (rows
+// 8g+4h .. 8g+4h+3), software-pipelined one step ahead.
+struct DiagCol { float4 g[4]; float d; };
+__device__ __forceinline__ void diag_load(DiagCol& c, const float* Lc, int i, int h) {
+    const float4* p = reinterpret_cast<const float4*>(Lc + i * 32 + 4 * h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        if (8 * g + 7 > i) c.g[g] = p[2 * g];  // compile-time prune (i is a constant after unrolling)
+    c.d = Lc[i * 32 + i];
+}
+template <bool PIPE>
+__device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) {
+    DiagCol cur, nxt;
+    diag_load(cur, Lc, 0, h);
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        if (PIPE && i + 1 < 32) diag_load(nxt, Lc, i + 1, h);
+        const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
+        float cand = v[ri] / cur.d;
+        // broadcast row i from the half that owns it: v_permlane32_swap gives {low-half copy, high-half copy}
+        unsigned cu = __float_as_uint(cand);
+        auto sw = __builtin_amdgcn_permlane32_swap(cu, cu, false, false);
+        float vi = __uint_as_float(hi_ ? sw[1] : sw[0]);
+        v[ri] = (h == hi_) ? vi : v[ri];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row0 = (r & 3) + 8 * (r >> 2);
+            if (row0 + 4 > i) {
+                const int row = row0 + 4 * h;
+                const float4 q = cur.g[r >> 2];
+                float lri = (r & 3) == 0 ? q.x : ((r & 3) == 1 ? q.y : ((r & 3) == 2 ? q.z : q.w));
+                float upd = fmaf(-lri, vi, v[r]);
+                v[r] = (row > i) ? upd : v[r];
+            }
+        }
+        if (PIPE) cur = nxt;
+        else if (i + 1 < 32) diag_load(cur, Lc, i + 1, h);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+
+}  // namespace gpis
