@@ -20,7 +20,10 @@ struct ClusterModel {
     int nb;     // ceil(K / 32)
     float scale;            // GP length scale
     float* L;               // [ld*ld] lower Cholesky factor
-    float* Lt;              // [nbr(nbr+1)/2][1024], nbr = ld/32: the same factor as 32x32 tiles in MFMA A-operand order
+    float* Lt;              // [nbr(nbr+1)/2][1024], nbr = ld/32: the NEGATED factor as 32x32 tiles.  Off-diagonal tile
+                            // (b, c): MFMA A-operand order.  Diagonal tile (c, c): column-major, strictly lower part
+                            // (negated), zero on and above the diagonal -- the layout the K4 in-register solve reads.
+    float* rdiag;           // [ld] 1 / L_kk (1 for the padding rows k >= K)
     float* alpha;           // [ld]
     float* x4;              // [N][4]  (x, y, z|0, 0)
     int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)
@@ -94,7 +97,6 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
-void ongpis_launch_tile(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;

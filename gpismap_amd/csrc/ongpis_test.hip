@@ -30,6 +30,9 @@ namespace gpis {
 typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const int __attribute__((address_space(1))) * giptr;
 typedef const float4 __attribute__((address_space(1))) * gf4ptr;
+typedef const void __attribute__((address_space(1))) * gvptr;
+typedef float __attribute__((address_space(3))) * lds_fptr;
+typedef void __attribute__((address_space(3))) * lds_vptr;
 typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // explicit LDS: volatile generic pointers become flat loads
 
 
@@ -73,23 +76,17 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #define TRACE() do { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
-    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
-        for (int i = 0; i < 12; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
         gfptr g_alpha = (gfptr)m.alpha;
         giptr g_ri = (giptr)m.rowinfo;
         gfptr g_x4 = (gfptr)m.x4;
-        if (!(A.dbg & 64)) for (int i = tid; i < ld; i += 64 * W) { s_alpha[i] = g_alpha[i]; s_ri[i] = g_ri[i]; }
-        if (!(A.dbg & 64)) for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
+        for (int i = tid; i < ld; i += 64 * W) { s_alpha[i] = g_alpha[i]; s_ri[i] = g_ri[i]; }
+        for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
         __syncthreads();
     }
     const float4* x4 = s_x4;
-    gfptr Lg = (gfptr)m.L;
-    // L through a buffer resource: one VGPR byte offset per lane + scalar offsets (no 64-bit VGPR addresses)
-    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.L, 0, (unsigned)ld * (unsigned)ld * 4u, 0x00020000);
-    const int Lvoff = (h * ld + l31) * 4;   // lane part of a column-major L tile access: row l31 of the tile, column h
-    // off-diagonal tiles come from the re-tiled copy Lt (MFMA A-operand order): 4 x 16-byte loads per tile
+    // off-diagonal tiles come from the re-tiled copy Lt (-L, MFMA A-operand order) through a buffer resource:
+    // one VGPR byte offset per lane + scalar offsets, 4 x 16-byte loads per tile
     const int ntl = nb * (nb + 1) / 2;
     const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
@@ -192,23 +189,29 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     // done[w] = last step whose updates wave w finished.  The owner of block c+1 updates that
     // tile first, solves it and publishes V_{c+1} while the other waves are still busy with
     // step c, so the diagonal solves of consecutive steps overlap with MFMA work of other waves.
+    // The owner chain (update -> solve -> publish) is the critical path of the workgroup: it runs
+    // at raised wave priority, scales pivot rows by precomputed reciprocals and reads its
+    // diagonal tile through an LDS-DMA copy issued before the wait.
     float ss = 0.f;  // partial sum of squares of V over this lane's rows
     lds_flag_ptr pub = flags;
     lds_flag_ptr done = flags + 1;
-    auto load_diag = [&](int c) {
-        if (A.dbg & 128) return;
-        float* Lc = Lcr + (c % RING) * 1024;
-        const int sbase = (c * 32 * ld + c * 32) * 4;
+    gfptr g_rd = (gfptr)m.rdiag;
+    gfptr g_lt = (gfptr)m.Lt;
+    float rl = 1.f;
+    auto load_diag = [&](int c) {   // diagonal tile (solve layout) straight into its LDS ring slot, 4 x 1 KiB
+        gfptr src = g_lt + (size_t)(c * (c + 1) / 2 + c) * 1024 + lane * 4;
+        lds_fptr dst = (lds_fptr)(Lcr + (c % RING) * 1024);
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc)
-            Lc[(2 * cc + h) * 32 + l31] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, sbase + 2 * cc * ld * 4, 0));
+        for (int g = 0; g < 4; ++g)
+            __builtin_amdgcn_global_load_lds((gvptr)(src + g * 256), (lds_vptr)(dst + g * 256), 16, 0, 0);
+        rl = g_rd[c * 32 + l31];
     };
     auto solve_publish = [&](f32x16& v, int c) {
-        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0): the diagonal tile has landed in LDS
         __builtin_amdgcn_wave_barrier();
-        if (!(A.dbg & 2)) diag_solve32<(NBW <= 4)>(v, Lcr + (c % RING) * 1024, h);
+        if (!(A.dbg & 2)) diag_solve32_rcp<(NBW <= 4)>(v, Lcr + (c % RING) * 1024, rl, h);
         // ring slot free once every wave has finished step c - RING
-        if (c >= RING && !(A.dbg & 256)) {
+        if (c >= RING) {
 #pragma unroll 1
             for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
         }
@@ -222,18 +225,14 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) *pub = c;
     };
-    auto update_tile = [&](f32x16& a_, const float* Vb, const float (&av)[16]) {
+    // av = -L tile operands (Lt holds the negated factor), vb = V_c in MFMA B-operand order
+    auto update_tile = [&](f32x16& a_, const float (&vb)[16], const float (&av)[16]) {
         if (A.dbg & 4) return;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
-            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(-av[kk], Vb[(2 * kk + h) * 32 + l31], a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], vb[kk], a_, 0, 0, 0);
     };
     auto load_a = [&](float (&av)[16], int b, int c) {
-        if (A.dbg & 16) {
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) av[kk] = 1.f;
-            return;
-        }
         const int sbase = (b * (b + 1) / 2 + c) * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -243,7 +242,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
         }
     };
 
-    if (wave == 0 && !(A.dbg & 32)) {  // block 0 has no dependency
+    if (wave == 0) {  // block 0 has no dependency
         load_diag(0);
         solve_publish(acc[0], 0);
     }
@@ -255,39 +254,49 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #pragma unroll 1
         for (int wc = 0; wc < W; ++wc) {
             const int c = tc * W + wc;
-            if (c >= nb || (A.dbg & 32)) break;
+            if (c >= nb) break;
             const bool has_next = (c + 1 < nb);
             const bool own_same = has_next && (wc + 1 < W) && (wave == wc + 1);
             const bool own_next = has_next && (wc + 1 == W) && (wave == 0) && (tc + 1 < NBW);
+            const bool owner = own_same || own_next;
+            auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
             float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
-            if (own_same || own_next) { load_diag(c + 1); load_a(avp[0], c + 1, c); }   // issue before waiting
+            float vb[16];
+            // issue the loads this step needs before waiting for V_c
+            if (owner) { load_diag(c + 1); load_a(avp[0], c + 1, c); }
+            else if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             TRACE();
-            if (!(A.dbg & 256)) while (*pub < c) __builtin_amdgcn_s_sleep(1);
+            while (*pub < c) __builtin_amdgcn_s_sleep(1);
             TRACE();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const float* Vb = Vbuf + (c % RING) * 1024;
-            if (own_same) {
-                update_tile(acc[tc], Vb, avp[0]);
-                solve_publish(acc[tc], c + 1);
+            {
+                const float* Vb = Vbuf + (c % RING) * 1024;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[(2 * kk + h) * 32 + l31];
             }
-            if (tc + 1 < NBW) {
-                if (own_next) {
-                    update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], Vb, avp[0]);
-                    solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
+            if (owner) {
+                __builtin_amdgcn_s_setprio(3);
+                if (own_same) {
+                    update_tile(acc[tc], vb, avp[0]);
+                    solve_publish(acc[tc], c + 1);
                 }
+                if (tc + 1 < NBW) {
+                    if (own_next) {
+                        update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], vb, avp[0]);
+                        solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+                if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             }
             TRACE();
             __builtin_amdgcn_sched_barrier(0);
             // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
-            {
-                auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
-                if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
 #pragma unroll
-                for (int t = tc; t < NBW; ++t) {
-                    if (t + 1 < NBW) { if (active(t + 1)) load_a(avp[(t + 1) & 1], wave + W * (t + 1), c); }
-                    if (active(t)) update_tile(acc[t], Vb, avp[t & 1]);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            for (int t = tc; t < NBW; ++t) {
+                if (t + 1 < NBW) { if (active(t + 1)) load_a(avp[(t + 1) & 1], wave + W * (t + 1), c); }
+                if (active(t)) update_tile(acc[t], vb, avp[t & 1]);
+                __builtin_amdgcn_sched_barrier(0);
             }
             TRACE();
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");

@@ -156,8 +156,9 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 //   tile(bi, j) = A(bi, j) - sum_{p<j} L(bi, p) L(j, p)^T      v_mfma_f32_32x32x2_f32, ascending p and k
 //   diagonal tile: factorised in LDS by wave 0 (column steps, lane = row)
 //   other tiles:   X L_jj^T = T solved in registers with the same routine K4 uses (diag_solve32)
-// Operands come from the re-tiled copy Lt (MFMA A-operand order, 4 x 16-byte loads per tile), which is
-// produced on the fly together with the column-major factor.  No read-modify-write of the trailing
+// Operands come from the re-tiled copy Lt (-L in MFMA A-operand order, 4 x 16-byte loads per tile), which is
+// produced on the fly together with the column-major factor; its diagonal tiles and rdiag are laid out
+// for K4's in-register solve (ongpis.h).  No read-modify-write of the trailing
 // matrix through memory.  The per-element operation order is the ascending-k fmaf chain of
 // dev_common.h: results are bit-identical to the unblocked chain.
 // ---------------------------------------------------------------------------
@@ -182,13 +183,14 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
     const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
 
-    auto load_tile = [&](float (&o)[16], int b, int c) {   // Lt(b, c) in A-operand order
+    // Lt(b, c) in A-operand order.  The tiles hold -L; SIGN flips them back on load (0x80000000) or not (0).
+    auto load_tile = [&](float (&o)[16], int b, int c, unsigned sign) {
         const int sbase = tri_index(b, c) * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + g * 1024, 0);
-            o[4 * g + 0] = __uint_as_float(q[0]); o[4 * g + 1] = __uint_as_float(q[1]);
-            o[4 * g + 2] = __uint_as_float(q[2]); o[4 * g + 3] = __uint_as_float(q[3]);
+            o[4 * g + 0] = __uint_as_float(q[0] ^ sign); o[4 * g + 1] = __uint_as_float(q[1] ^ sign);
+            o[4 * g + 2] = __uint_as_float(q[2] ^ sign); o[4 * g + 3] = __uint_as_float(q[3] ^ sign);
         }
     };
 
@@ -213,31 +215,31 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
             }
             if (act[0]) {
                 float a_[2][16];
-                if (j > 0) load_tile(a_[0], j, 0);
+                if (j > 0) load_tile(a_[0], j, 0, 0x80000000u);   // a_ = +L(j, p)
 #pragma unroll 1
                 for (int p = 0; p < j; p += 2) {
                     // two panels per iteration so the double buffer index stays static
-                    if (p + 1 < j) load_tile(a_[1], j, p + 1);
+                    if (p + 1 < j) load_tile(a_[1], j, p + 1, 0x80000000u);
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
                         if (act[tt]) {
                             float b_[16];
-                            load_tile(b_, j + wave + NW * (t0 + tt), p);
+                            load_tile(b_, j + wave + NW * (t0 + tt), p, 0u);   // b_ = -L(bi, p)
 #pragma unroll
                             for (int kk = 0; kk < 16; ++kk)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], b_[kk], acc[tt], 0, 0, 0);
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0][kk], b_[kk], acc[tt], 0, 0, 0);
                         }
                     }
                     if (p + 1 < j) {
-                        if (p + 2 < j) load_tile(a_[0], j, p + 2);
+                        if (p + 2 < j) load_tile(a_[0], j, p + 2, 0x80000000u);
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) {
                             if (act[tt]) {
                                 float b_[16];
-                                load_tile(b_, j + wave + NW * (t0 + tt), p + 1);
+                                load_tile(b_, j + wave + NW * (t0 + tt), p + 1, 0u);
 #pragma unroll
                                 for (int kk = 0; kk < 16; ++kk)
-                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], b_[kk], acc[tt], 0, 0, 0);
+                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1][kk], b_[kk], acc[tt], 0, 0, 0);
                             }
                         }
                     }
@@ -266,12 +268,16 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                     }
                     __builtin_amdgcn_wave_barrier();
                     // column-major copy for the solves, and the factor itself to global memory (lower part)
+                    // and the diagonal tile of Lt in K4's solve layout (-L strictly below the diagonal, else 0) + 1/L_kk
                     if (lane < 32) {
+                        float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024;
                         for (int c = 0; c < 32; ++c) {
                             float v = Dv[lane * 33 + c];
                             Lc[c * 32 + lane] = v;
                             if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                            Dt[c * 32 + lane] = (c < lane && lane < pw) ? -v : 0.f;
                         }
+                        m.rdiag[j * 32 + lane] = (lane < pw) ? 1.0f / Dv[lane * 33 + lane] : 1.0f;
                     }
                 }
                 __syncthreads();
@@ -288,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                     {
                         float* T = Tt[wave];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = acc[tt][r];
+                        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[tt][r];   // Lt holds -L
                         __builtin_amdgcn_s_waitcnt(0xc07f);
                         __builtin_amdgcn_wave_barrier();
                         float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
@@ -349,47 +355,12 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
 }
 
-// ---------------------------------------------------------------------------
-// Re-tile the factor for K4: block (b, c), b >= c, is stored as 1024 consecutive floats in the
-// order the MFMA A operand consumes it -- [g][lane][j] holds L[32b + (lane&31)][32c + 2(4g+j) + (lane>>5)]
-// -- so a lane fetches its 16 operands of a tile with four 16-byte loads.  grid = jobs, block = 256.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ongpis_tile_kernel(const ClusterModel* __restrict__ models,
-                                                          const int* __restrict__ d_jobs) {
-    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const ClusterModel m = models[JOB_MODEL(job)];
-    const int nb = m.nb, ld = m.ld;
-    const int ntiles = nb * (nb + 1) / 2;
-    const int h = lane >> 5, l31 = lane & 31;
-    for (int t = wave; t < ntiles; t += 4) {
-        // t = b(b+1)/2 + c
-        int b = (int)((sqrtf(8.f * t + 1.f) - 1.f) * 0.5f);
-        while ((b + 1) * (b + 2) / 2 <= t) ++b;
-        while (b * (b + 1) / 2 > t) --b;
-        int c = t - b * (b + 1) / 2;
-        const float* src = m.L + (size_t)(b * 32 + l31) + (size_t)(c * 32 + h) * ld;
-        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)t * 1024);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float4 q;
-            q.x = src[(size_t)(2 * (4 * g + 0)) * ld];
-            q.y = src[(size_t)(2 * (4 * g + 1)) * ld];
-            q.z = src[(size_t)(2 * (4 * g + 2)) * ld];
-            q.w = src[(size_t)(2 * (4 * g + 3)) * ld];
-            dst[g * 64 + lane] = q;
-        }
-    }
-}
-
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_gather_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs, d_ids, d_pts, pts_cap);
 }
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
-}
-void ongpis_launch_tile(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
-    hipLaunchKernelGGL(ongpis_tile_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs);
 }
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL((ongpis_chol_kernel<3>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);

@@ -449,7 +449,7 @@ struct OnGPIS {
             const float* col = &ks[(size_t)c * K];
             mean[c] = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], alpha[r], acc); });
         }
-        fwd_subst(L.data(), K, K, ks.data(), nc, K);
+        fwd_subst_rcp(L.data(), K, K, ks.data(), nc, K);   // matrix rhs: reciprocal-scaled pivots (linalg.hpp)
         for (int c = 0; c < nc; ++c) {
             const float* col = &ks[(size_t)c * K];
             float s = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], col[r], acc); });

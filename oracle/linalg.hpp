@@ -64,6 +64,25 @@ static inline void fwd_subst(const float* L, int n, int ld, float* B, int nrhs, 
     }
 }
 
+// B <- L^{-1} B for a MATRIX right-hand side (the K x (1+dim) cross-covariance block of one test
+// point, OnGPIS.cpp:199).  For a matrix rhs Eigen dispatches to its blocked triangular-solve kernel,
+// which scales the pivot row by a precomputed reciprocal (a = 1/l_kk; b_k *= a) instead of dividing;
+// the vector overload above (used for alpha) divides.  Order (O1) otherwise.
+static inline void fwd_subst_rcp(const float* L, int n, int ld, float* B, int nrhs, int ldb) {
+    std::vector<float> rinv(n > 0 ? n : 1);
+    for (int k = 0; k < n; ++k) rinv[k] = 1.0f / L[k + (size_t)k * ld];
+    for (int c = 0; c < nrhs; ++c) {
+        float* b = B + (size_t)c * ldb;
+        for (int k = 0; k < n; ++k) {
+            const float* col = L + (size_t)k * ld;
+            float xk = b[k] * rinv[k];
+            b[k] = xk;
+            float nxk = -xk;
+            for (int j = k + 1; j < n; ++j) b[j] = fmaf(col[j], nxk, b[j]);
+        }
+    }
+}
+
 // b <- L^{-T} b (single rhs).  Order (O2): for row j the chain runs k = n-1 .. j+1.
 static inline void bwd_subst(const float* L, int n, int ld, float* b) {
     for (int j = n - 1; j >= 0; --j) {
