@@ -43,7 +43,8 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the ownership logic in SGPRs
     const int h = lane >> 5, l31 = lane & 31;
     const ClusterModel m = A.models[A.tile_model[tile]];
     const int N = m.N, K = m.K, ld = m.ld, nb = m.nb, dim = m.dim;
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                     const int rw = rowmap_t(r, h);
                     const float v = tbuf[rw * 36 + l31];
                     acc[t][r] = v;
-                    if (b * 32 + rw < K) mp = fmaf(v, s_alpha[b * 32 + rw], mp);
+                    mp = fmaf(v, s_alpha[b * 32 + rw], mp);   // rows >= K: B = 0 and alpha = 0 (K3 pads)
                 }
                 __builtin_amdgcn_wave_barrier();
             } else {
@@ -215,12 +216,13 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #pragma unroll 1
             for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
         }
-        float* Vw = Vbuf + (c % RING) * 1024;
+        // one lane pointer + compile-time row offsets; padding rows >= K hold exact zeros (ongpis_train.hip),
+        // so the sum of squares needs no row predicate
+        float* Vw = Vbuf + (c % RING) * 1024 + (4 * h * 32 + l31);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rw = rowmap_t(r, h);
-            Vw[rw * 32 + l31] = v[r];
-            if (c * 32 + rw < K) ss = fmaf(v[r], v[r], ss);
+            Vw[((r & 3) + 8 * (r >> 2)) * 32] = v[r];
+            ss = fmaf(v[r], v[r], ss);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) *pub = c;
@@ -269,26 +271,28 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             while (*pub < c) __builtin_amdgcn_s_sleep(1);
             TRACE();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            {
-                const float* Vb = Vbuf + (c % RING) * 1024;
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[(2 * kk + h) * 32 + l31];
-            }
+            const float* Vb = Vbuf + (c % RING) * 1024;
             if (owner) {
+                float vbo[16];   // the owner re-reads V_c after its solve: nothing but the tile stays live across it
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) vbo[kk] = Vb[(2 * kk + h) * 32 + l31];
                 __builtin_amdgcn_s_setprio(3);
                 if (own_same) {
-                    update_tile(acc[tc], vb, avp[0]);
+                    update_tile(acc[tc], vbo, avp[0]);
                     solve_publish(acc[tc], c + 1);
                 }
                 if (tc + 1 < NBW) {
                     if (own_next) {
-                        update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], vb, avp[0]);
+                        update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], vbo, avp[0]);
                         solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
                     }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[(2 * kk + h) * 32 + l31];
             TRACE();
             __builtin_amdgcn_sched_barrier(0);
             // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead

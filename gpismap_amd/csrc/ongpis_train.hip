@@ -353,6 +353,17 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
     // restore the identity in row K so the padded square is a valid triangular factor
     for (int jj = tid; jj < K; jj += 512) L[K + (size_t)jj * ld] = 0.f;
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
+    // K4 runs over whole 32-row blocks without row predicates: the padding rows K..32nb-1 must stay exactly
+    // zero through its solve, so alpha is zero there and row K (the y row) is cleared in the re-tiled copy too.
+    for (int jj = K + tid; jj < ld; jj += 512) m.alpha[jj] = 0.f;
+    if (K % 32 != 0) {
+        const int pr = K - 32 * (nb - 1);
+        for (int idx = tid; idx < (nb - 1) * 8; idx += 512) {
+            const int c = idx >> 3, g = (idx >> 1) & 3, hh = idx & 1;
+            float4* t = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(nb - 1, c) * 1024);
+            t[g * 64 + hh * 32 + pr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
 }
 
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
