@@ -37,8 +37,10 @@ typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // expl
 
 
 // Size classes (block rows nb = ceil(K/32)): W waves x NBW tiles per wave.
-//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 4x8   <= 64: 8x8   <= 96: 8x12
-template <int W, int NBW, int MINW>
+//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 8x4 (128 VGPRs)   <= 64: 8x8   <= 96: 8x12
+// VREG: V_c is read into registers once per step (256-VGPR classes) or streamed from LDS per MFMA pair
+// (128-VGPR classes, four waves per SIMD).  TR: cycle-trace build of the kernel (GPIS_K4_TRACE).
+template <int W, int NBW, int MINW, bool VREG, bool TR>
 __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -72,9 +74,9 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     if (qi < jcnt) xq = A.xq[A.job_q[joff + qi]];
 
     // optional cycle trace of one workgroup (A.trace != nullptr): [wave][slot] timestamps
-    unsigned long long* trc = (A.trace && blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
+    unsigned long long* trc = (TR && A.trace && blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
     int tri = 0;
-#define TRACE() do { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } while (0)
+#define TRACE() do { if constexpr (TR) { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
@@ -210,11 +212,10 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     auto solve_publish = [&](f32x16& v, int c) {
         __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0): the diagonal tile has landed in LDS
         __builtin_amdgcn_wave_barrier();
-        if (!(A.dbg & 2)) diag_solve32_rcp<(NBW <= 4)>(v, Lcr + (c % RING) * 1024, rl, h);
+        if (!(A.dbg & 2)) diag_solve32_rcp<(VREG && NBW <= 4)>(v, Lcr + (c % RING) * 1024, rl, h);
         // ring slot free once every wave has finished step c - RING
-        if (c >= RING) {
-#pragma unroll 1
-            for (int w = 0; w < W; ++w) while (done[w] < c - RING) __builtin_amdgcn_s_sleep(1);
+        if (c >= RING) {   // one LDS round trip: lane w looks at done[w]
+            while (__builtin_amdgcn_ballot_w64(lane < W && done[lane < W ? lane : 0] < c - RING)) __builtin_amdgcn_s_sleep(1);
         }
         // one lane pointer + compile-time row offsets; padding rows >= K hold exact zeros (ongpis_train.hip),
         // so the sum of squares needs no row predicate
@@ -233,6 +234,19 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
             a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], vb[kk], a_, 0, 0, 0);
+    };
+    // same, V_c streamed from its LDS ring slot one MFMA pair ahead
+    auto update_tile_lds = [&](f32x16& a_, const float* Vl, const float (&av)[16]) {
+        if (A.dbg & 4) return;
+        float p0 = Vl[0], p1 = Vl[64];
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            float n0 = 0.f, n1 = 0.f;
+            if (kk + 2 < 16) { n0 = Vl[(kk + 2) * 64]; n1 = Vl[(kk + 3) * 64]; }
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], p0, a_, 0, 0, 0);
+            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk + 1], p1, a_, 0, 0, 0);
+            p0 = n0; p1 = n1;
+        }
     };
     auto load_a = [&](float (&av)[16], int b, int c) {
         const int sbase = (b * (b + 1) / 2 + c) * 4096;
@@ -263,7 +277,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             const bool owner = own_same || own_next;
             auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
             float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
-            float vb[16];
+            float vb[VREG ? 16 : 1];
             // issue the loads this step needs before waiting for V_c
             if (owner) { load_diag(c + 1); load_a(avp[0], c + 1, c); }
             else if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
@@ -271,35 +285,42 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             while (*pub < c) __builtin_amdgcn_s_sleep(1);
             TRACE();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            const float* Vb = Vbuf + (c % RING) * 1024;
+            const float* Vb = Vbuf + (c % RING) * 1024 + (h * 32 + l31);   // B operand kk: Vb[64 kk]
             if (owner) {
-                float vbo[16];   // the owner re-reads V_c after its solve: nothing but the tile stays live across it
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) vbo[kk] = Vb[(2 * kk + h) * 32 + l31];
                 __builtin_amdgcn_s_setprio(3);
-                if (own_same) {
-                    update_tile(acc[tc], vbo, avp[0]);
-                    solve_publish(acc[tc], c + 1);
-                }
-                if (tc + 1 < NBW) {
-                    if (own_next) {
-                        update_tile(acc[tc + 1 < NBW ? tc + 1 : tc], vbo, avp[0]);
-                        solve_publish(acc[tc + 1 < NBW ? tc + 1 : tc], c + 1);
+                auto own_tile = [&](f32x16& a_) {
+                    if constexpr (VREG) {
+                        float vbo[16];   // the owner re-reads V_c after its solve: nothing but the tile stays live across it
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) vbo[kk] = Vb[64 * kk];
+                        update_tile(a_, vbo, avp[0]);
+                    } else {
+                        update_tile_lds(a_, Vb, avp[0]);
                     }
+                    solve_publish(a_, c + 1);
+                };
+                if (own_same) own_tile(acc[tc]);
+                if (tc + 1 < NBW) {
+                    if (own_next) own_tile(acc[tc + 1 < NBW ? tc + 1 : tc]);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             }
             __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VREG) {
 #pragma unroll
-            for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[(2 * kk + h) * 32 + l31];
+                for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[64 * kk];
+            }
             TRACE();
             __builtin_amdgcn_sched_barrier(0);
             // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
 #pragma unroll
             for (int t = tc; t < NBW; ++t) {
                 if (t + 1 < NBW) { if (active(t + 1)) load_a(avp[(t + 1) & 1], wave + W * (t + 1), c); }
-                if (active(t)) update_tile(acc[t], vb, avp[t & 1]);
+                if (active(t)) {
+                    if constexpr (VREG) update_tile(acc[t], vb, avp[t & 1]);
+                    else update_tile_lds(acc[t], Vb, avp[t & 1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             TRACE();
@@ -310,7 +331,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     __syncthreads();
 
     TRACE();
-    if (trc && lane == 0) trc[511] = tri;
+    if constexpr (TR) { if (trc && lane == 0) trc[511] = tri; }
     // ---- stage 4: reduce partials (lane halves, then waves in fixed order) ----
     mp = mp + __shfl_xor(mp, 32);
     ss = ss + __shfl_xor(ss, 32);
@@ -331,7 +352,8 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     }
 }
 
-static const int kClassW[6] = {1, 2, 4, 4, 8, 8};
+// Size classes by nb = ceil(K/32): W waves x NBW tiles per wave (ongpis.h, ongpis_class_of_nb).
+static const int kClassW[6] = {1, 2, 4, 8, 8, 8};
 static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
 
 static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
@@ -360,25 +382,20 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
     if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
     if (lds > budget) return GPIS_ERR_LIMIT;
+    typedef void (*kern_t)(EvalArgs);
+    static const kern_t kern[ONGPIS_NCLASS] = {
+        ongpis_eval_kernel<1, 4, 2, true, false>, ongpis_eval_kernel<2, 4, 2, true, false>,
+        ongpis_eval_kernel<4, 4, 2, true, false>, ongpis_eval_kernel<8, 4, 4, false, false>,
+        ongpis_eval_kernel<8, 8, 2, true, false>, ongpis_eval_kernel<8, 12, 2, true, false>};
+    static const kern_t kern_tr = ongpis_eval_kernel<8, 4, 4, false, true>;   // traced build of class 3
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<1, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<2, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<4, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ongpis_eval_kernel<8, 12, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int i = 0; i < ONGPIS_NCLASS; ++i)
+            (void)hipFuncSetAttribute((const void*)kern[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    switch (wclass) {
-        case 0: hipLaunchKernelGGL((ongpis_eval_kernel<1, 4, 2>), dim3(ntiles), dim3(64), lds, s, args); break;
-        case 1: hipLaunchKernelGGL((ongpis_eval_kernel<2, 4, 2>), dim3(ntiles), dim3(128), lds, s, args); break;
-        case 2: hipLaunchKernelGGL((ongpis_eval_kernel<4, 4, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
-        case 3: hipLaunchKernelGGL((ongpis_eval_kernel<4, 8, 2>), dim3(ntiles), dim3(256), lds, s, args); break;
-        case 4: hipLaunchKernelGGL((ongpis_eval_kernel<8, 8, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
-        case 5: hipLaunchKernelGGL((ongpis_eval_kernel<8, 12, 2>), dim3(ntiles), dim3(512), lds, s, args); break;
-        default: return GPIS_ERR_ARG;
-    }
+    hipLaunchKernelGGL((args.trace && wclass == 3) ? kern_tr : kern[wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
     if (args.trace && wclass == 3) {
         (void)hipStreamSynchronize(s);
         static unsigned long long h[512 * 16];
