@@ -20,10 +20,10 @@ struct ClusterModel {
     int nb;     // ceil(K / 32)
     float scale;            // GP length scale
     float* L;               // [ld*ld] lower Cholesky factor
-    float* Lt;              // [nbr(nbr+1)/2][1024], nbr = ld/32: the NEGATED factor as 32x32 tiles.  Off-diagonal tile
-                            // (b, c): MFMA A-operand order.  Diagonal tile (c, c): column-major, strictly lower part
-                            // (negated), zero on and above the diagonal -- the layout the K4 in-register solve reads.
-    float* rdiag;           // [ld] 1 / L_kk (1 for the padding rows k >= K)
+    float* Lt;              // [nbr(nbr+1)/2][1024], nbr = ld/32: 32x32 tiles in MFMA A-operand order, 4 x 16 B per lane:
+                            // [g][lane][j] = T[lane & 31][k(4g + j, lane >> 5)].  Off-diagonal tile (b, c): T = -L_bc,
+                            // k(kk, h) = 2 kk + h.  Diagonal tile (c, c): T = inv(L_cc) (identity-padded),
+                            // k(kk, h) = (kk & 3) + 8 (kk >> 2) + 4 h, the row of an accumulator tile register.
     float* alpha;           // [ld]
     float* x4;              // [N][4]  (x, y, z|0, 0)
     int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)

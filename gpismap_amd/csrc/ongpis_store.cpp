@@ -61,8 +61,7 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
     int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     size_t oT = align_up(oG + szG, 256), szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
-    size_t oD = align_up(oT + szT, 256), szD = sizeof(float) * ld;
-    size_t total = align_up(oD + szD, 256);
+    size_t total = align_up(oT + szT, 256);
     if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
     char* base = (char*)pool_alloc(pool_, total);
     if (!base) return GPIS_ERR_HIP;
@@ -70,7 +69,6 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
     m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
     m.Lt = (float*)(base + oT);
-    m.rdiag = (float*)(base + oD);
     m.base = base;
     dirty_ = true;
     return GPIS_OK;

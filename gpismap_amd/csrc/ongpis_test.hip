@@ -12,14 +12,15 @@
 // L V = B by a right-looking 32-blocked forward substitution:
 //   * block row b of B lives in the accumulator registers of wave (b mod W)
 //     for the whole solve (f32x16 per 32x32 tile, MFMA C/D layout);
-//   * step c: the owner of block c solves the 32x32 diagonal system in
-//     registers (true divisions, ascending fmaf chain), publishes V_c to LDS;
+//   * step c: the owner of block c multiplies its tile by the inverted diagonal block
+//     (V_c = inv(L_cc) U_c, 16 matrix instructions; the inverse comes from K3) and publishes V_c to LDS;
 //   * every wave then applies  B_b -= L_bc V_c  to its tiles with
 //     v_mfma_f32_32x32x2_f32, streaming L_bc from L2/HBM exactly once.
 // Each L element is read once per workgroup and used for 32 columns.  The
 // per-element operation order is the ascending-k fmaf chain of dev_common.h.
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 #include "ongpis.h"
 #include "tile_solve.h"
 
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     const int joff = A.tile_off[tile], jcnt = A.tile_cnt[tile];
 
     // LDS carve (all dynamic, 16-byte aligned pieces).  Region U is time-shared: stage 1/2 keep the
-    // per-lane staging strips and the exp table there, stage 3 the V ring and the diagonal-block ring.
+    // per-lane staging strips and the exp table there, stage 3 the ring of published V blocks.
     float* red = reinterpret_cast<float*>(smem);                  // [W][64][2]
     lds_flag_ptr flags = (lds_flag_ptr)(red + W * 128);           // [0] = pub, [1..W] = done[w]; 32 ints reserved
     float* s_alpha = red + W * 128 + 32;                          // [ld]
@@ -63,7 +64,6 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     float* stage = U;                                             // stage 2: [W][32*36] per-wave padded tile
     double* etab = reinterpret_cast<double*>(U + W * 1152);       // stage 1/2: [N][8] exp table (optional)
     float* Vbuf = U;                                              // stage 3: [RING][32*32] published V blocks
-    float* Lcr = U + RING * 1024;                                 // stage 3: [RING][32*32] diagonal blocks (column-major)
 
     const float a = (float)(sqrt(3.0) / (double)m.scale);
 
@@ -77,8 +77,14 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     unsigned long long* trc = (TR && A.trace && blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
     int tri = 0;
 #define TRACE() do { if constexpr (TR) { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } } while (0)
+    // owner-path events (traced build): [8 + wave][slot]
+    int tro = 0;
+#define TRACE_OWN() do { if constexpr (TR) { if (trc && lane == 0 && tro < 511) trc[8 * 512 + tro++] = __builtin_readcyclecounter(); } } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
+    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
+        for (int i = 0; i < (A.dbg >> 10); ++i) __builtin_amdgcn_s_sleep(127);
+    }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
         gfptr g_alpha = (gfptr)m.alpha;
         giptr g_ri = (giptr)m.rowinfo;
@@ -190,29 +196,24 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     __syncthreads();  // staging strips alias the rings
     // Dataflow synchronisation instead of a barrier per step: `pub` = last published block,
     // done[w] = last step whose updates wave w finished.  The owner of block c+1 updates that
-    // tile first, solves it and publishes V_{c+1} while the other waves are still busy with
-    // step c, so the diagonal solves of consecutive steps overlap with MFMA work of other waves.
-    // The owner chain (update -> solve -> publish) is the critical path of the workgroup: it runs
-    // at raised wave priority, scales pivot rows by precomputed reciprocals and reads its
-    // diagonal tile through an LDS-DMA copy issued before the wait.
+    // tile first, turns it into V_{c+1} and publishes it while the other waves are still busy with
+    // step c.  The owner chain (update -> V = inv(L_cc) U -> publish) is the critical path of the
+    // workgroup; it is two dependent runs of 16 matrix instructions -- the accumulator tile itself is the
+    // B operand of the second run (Lt's diagonal tiles are stored in the matching k order) -- and
+    // executes at raised wave priority.
     float ss = 0.f;  // partial sum of squares of V over this lane's rows
     lds_flag_ptr pub = flags;
     lds_flag_ptr done = flags + 1;
-    gfptr g_rd = (gfptr)m.rdiag;
-    gfptr g_lt = (gfptr)m.Lt;
-    float rl = 1.f;
-    auto load_diag = [&](int c) {   // diagonal tile (solve layout) straight into its LDS ring slot, 4 x 1 KiB
-        gfptr src = g_lt + (size_t)(c * (c + 1) / 2 + c) * 1024 + lane * 4;
-        lds_fptr dst = (lds_fptr)(Lcr + (c % RING) * 1024);
+    // u = U_c (C/D layout), ai = inv(L_cc) operands; returns with V_c published and its squares summed
+    auto invert_publish = [&](const f32x16& u, const float (&ai)[16], int c) {
+        f32x16 v;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            __builtin_amdgcn_global_load_lds((gvptr)(src + g * 256), (lds_vptr)(dst + g * 256), 16, 0, 0);
-        rl = g_rd[c * 32 + l31];
-    };
-    auto solve_publish = [&](f32x16& v, int c) {
-        __builtin_amdgcn_s_waitcnt(0);       // vmcnt(0): the diagonal tile has landed in LDS
-        __builtin_amdgcn_wave_barrier();
-        if (!(A.dbg & 2)) diag_solve32_rcp<(VREG && NBW <= 4)>(v, Lcr + (c % RING) * 1024, rl, h);
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+        if (!(A.dbg & 2)) {
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], u[kk], v, 0, 0, 0);
+        }
+        TRACE_OWN();
         // ring slot free once every wave has finished step c - RING
         if (c >= RING) {   // one LDS round trip: lane w looks at done[w]
             while (__builtin_amdgcn_ballot_w64(lane < W && done[lane < W ? lane : 0] < c - RING)) __builtin_amdgcn_s_sleep(1);
@@ -227,6 +228,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) *pub = c;
+        TRACE_OWN();   // published
     };
     // av = -L tile operands (Lt holds the negated factor), vb = V_c in MFMA B-operand order
     auto update_tile = [&](f32x16& a_, const float (&vb)[16], const float (&av)[16]) {
@@ -259,8 +261,9 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     };
 
     if (wave == 0) {  // block 0 has no dependency
-        load_diag(0);
-        solve_publish(acc[0], 0);
+        float ai[16];
+        load_a(ai, 0, 0);
+        invert_publish(acc[0], ai, 0);
     }
     // Steps c = tc*W + wc.  Block c+1 belongs to wave (wc+1) mod W; its tile index is tc (same
     // group) or tc+1 (wave 0 at the group boundary): static after unrolling tc, so the solve
@@ -279,7 +282,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
             float vb[VREG ? 16 : 1];
             // issue the loads this step needs before waiting for V_c
-            if (owner) { load_diag(c + 1); load_a(avp[0], c + 1, c); }
+            if (owner) { load_a(avp[0], c + 1, c); load_a(avp[1], c + 1, c + 1); }   // [1]: inv(L_{c+1,c+1})
             else if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             TRACE();
             while (*pub < c) __builtin_amdgcn_s_sleep(1);
@@ -289,15 +292,17 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             if (owner) {
                 __builtin_amdgcn_s_setprio(3);
                 auto own_tile = [&](f32x16& a_) {
+                    if constexpr (TR) { TRACE_OWN(); __builtin_amdgcn_s_waitcnt(0x0f70); TRACE_OWN(); }   // vmcnt(0): A operands arrived
                     if constexpr (VREG) {
-                        float vbo[16];   // the owner re-reads V_c after its solve: nothing but the tile stays live across it
+                        float vbo[16];
 #pragma unroll
                         for (int kk = 0; kk < 16; ++kk) vbo[kk] = Vb[64 * kk];
                         update_tile(a_, vbo, avp[0]);
                     } else {
                         update_tile_lds(a_, Vb, avp[0]);
                     }
-                    solve_publish(a_, c + 1);
+                    TRACE_OWN();
+                    invert_publish(a_, avp[1], c + 1);
                 };
                 if (own_same) own_tile(acc[tc]);
                 if (tc + 1 < NBW) {
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     __syncthreads();
 
     TRACE();
-    if constexpr (TR) { if (trc && lane == 0) trc[511] = tri; }
+    if constexpr (TR) { if (trc && lane == 0) { trc[511] = tri; trc[8 * 512 + 511] = tro; } }
     // ---- stage 4: reduce partials (lane halves, then waves in fixed order) ----
     mp = mp + __shfl_xor(mp, 32);
     ss = ss + __shfl_xor(ss, 32);
@@ -359,7 +364,7 @@ static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
 static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
     size_t fixed = sizeof(float) * (W * 128 + 32) + sizeof(float) * 2 * (size_t)maxLd + 16 * (size_t)maxN;
     size_t s2 = sizeof(float) * (size_t)W * 1152 + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
-    size_t s3 = sizeof(float) * 2 * 4 * 1024;   // RING = 4
+    size_t s3 = sizeof(float) * 4 * 1024;   // RING = 4 published V blocks
     return fixed + std::max(s2, s3);
 }
 
@@ -402,7 +407,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
         (void)hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost);
         FILE* f = fopen("gpurun_out/k4_trace.txt", "w");
         if (f) {
-            for (int w = 0; w < W; ++w) {
+            for (int w = 0; w < 2 * W; ++w) {   // rows W..2W-1: owner-path events
                 int n = (int)h[w * 512 + 511];
                 fprintf(f, "wave %d n %d\n", w, n);
                 for (int i = 0; i < n && i < 511; ++i) fprintf(f, "%llu\n", h[w * 512 + i] - h[0]);

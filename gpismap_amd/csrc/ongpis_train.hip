@@ -157,8 +157,8 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 //   diagonal tile: factorised in LDS by wave 0 (column steps, lane = row)
 //   other tiles:   X L_jj^T = T solved in registers with the same routine K4 uses (diag_solve32)
 // Operands come from the re-tiled copy Lt (-L in MFMA A-operand order, 4 x 16-byte loads per tile), which is
-// produced on the fly together with the column-major factor; its diagonal tiles and rdiag are laid out
-// for K4's in-register solve (ongpis.h).  No read-modify-write of the trailing
+// produced on the fly together with the column-major factor; its diagonal tiles hold the inverted diagonal
+// blocks K4 multiplies with (ongpis.h).  No read-modify-write of the trailing
 // matrix through memory.  The per-element operation order is the ascending-k fmaf chain of
 // dev_common.h: results are bit-identical to the unblocked chain.
 // ---------------------------------------------------------------------------
@@ -268,16 +268,13 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                     }
                     __builtin_amdgcn_wave_barrier();
                     // column-major copy for the solves, and the factor itself to global memory (lower part)
-                    // and the diagonal tile of Lt in K4's solve layout (-L strictly below the diagonal, else 0) + 1/L_kk
+                    // (identity-padded past the last row of a partial block: the padding rows of K4's solve stay zero)
                     if (lane < 32) {
-                        float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024;
                         for (int c = 0; c < 32; ++c) {
                             float v = Dv[lane * 33 + c];
-                            Lc[c * 32 + lane] = v;
+                            Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
                             if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
-                            Dt[c * 32 + lane] = (c < lane && lane < pw) ? -v : 0.f;
                         }
-                        m.rdiag[j * 32 + lane] = (lane < pw) ? 1.0f / Dv[lane * 33 + lane] : 1.0f;
                     }
                 }
                 __syncthreads();
@@ -286,6 +283,18 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
                 const int bi = j + wave + NW * (t0 + tt);
+                if (t0 == 0 && tt == 0 && wave == 0) {
+                    // inv(L_jj) for K4 (V_c = inv(L_cc) U_c on the matrix cores): forward substitution on the unit
+                    // vectors, stored as the diagonal tile of Lt in the order K4's MFMA A operand reads it --
+                    // step kk of lane (h', row) multiplies row k = rowmap(kk, h') of the accumulator tile
+                    f32x16 x;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
+                    diag_solve32<true>(x, Lc, h);
+                    float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
+                }
                 if (act[tt] && bi != j) {
                     diag_solve32<true>(acc[tt], Lc, h);
                     float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;

@@ -59,8 +59,8 @@ __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) 
 // above the diagonal, every later register simply takes fma(-l, v_i, .) -- two rows per v_pk_fma_f32, no
 // per-row selects: rows <= i see l = 0 and keep their value.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool PIPE>
-__device__ __forceinline__ void diag_solve32_rcp(f32x16& v, const float* Ls, float rl, int h) {
+template <bool PIPE, class Probe>
+__device__ __forceinline__ void diag_solve32_rcp(f32x16& v, const float* Ls, float rl, int h, Probe&& probe) {
     const float4* base = reinterpret_cast<const float4*>(Ls) + h;   // column i, rows 8g+4h..+3: base[8 i + 2 g]
     float4 cur[4], nxt[4];
 #pragma unroll
@@ -72,6 +72,7 @@ __device__ __forceinline__ void diag_solve32_rcp(f32x16& v, const float* Ls, flo
             for (int g = 0; g < 4; ++g)
                 if (8 * g + 7 > i + 1) nxt[g] = base[8 * (i + 1) + 2 * g];
         }
+        if ((i & 7) == 0) probe();   // cycle-trace hook of the traced K4 build (empty otherwise)
         const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
         const float rinv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rl), i));
         const float cand = v[ri] * rinv;

@@ -381,6 +381,7 @@ struct OnGPIS {
     std::vector<float> x;
     std::vector<int> gidx;
     std::vector<float> L, alpha;
+    std::vector<float> Linv;   // inverted 32x32 diagonal blocks of L (linalg.hpp, fwd_subst_blocked)
 
     OnGPIS(int dim_, float s) : dim(dim_), scale(s), three_over_scale((float)(3.0 / (double)(s * s))) {}
 
@@ -412,6 +413,7 @@ struct OnGPIS {
         alpha = y;
         fwd_subst(L.data(), K, K, alpha.data(), 1, K);
         bwd_subst(L.data(), K, K, alpha.data());
+        blocked_diag_inverses(L.data(), K, K, Linv);
         trained = true;
     }
 
@@ -449,7 +451,7 @@ struct OnGPIS {
             const float* col = &ks[(size_t)c * K];
             mean[c] = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], alpha[r], acc); });
         }
-        fwd_subst_rcp(L.data(), K, K, ks.data(), nc, K);   // matrix rhs: reciprocal-scaled pivots (linalg.hpp)
+        fwd_subst_blocked(L.data(), Linv.data(), K, K, ks.data(), nc, K);   // matrix rhs: blocked solve (linalg.hpp)
         for (int c = 0; c < nc; ++c) {
             const float* col = &ks[(size_t)c * K];
             float s = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], col[r], acc); });

@@ -17,7 +17,8 @@
 //        ascending k:   s = a_ij; s = fmaf(-l_ik, l_jk, s), k = 0..j-1
 //   (O2) backward substitution: one fmaf chain over DEscending k.
 //   (O3) long dot products / sums of squares in OnGPIS prediction: 2*W interleaved fmaf
-//        chains (gp.hpp, OnGPIS::reduce_O3); (O4)/(O5) ObsGP mean butterfly / variance chain.
+//        chains (gp.hpp, OnGPIS::reduce_O3); (O4)/(O5) ObsGP mean butterfly / variance chain;
+//   (O6) the product with an inverted diagonal block in the blocked matrix solve (below).
 //   sqrt and divide are IEEE correctly rounded.
 // Storage is column-major with leading dimension ld (as Eigen's MatrixXf).
 #pragma once
@@ -65,20 +66,53 @@ static inline void fwd_subst(const float* L, int n, int ld, float* B, int nrhs, 
 }
 
 // B <- L^{-1} B for a MATRIX right-hand side (the K x (1+dim) cross-covariance block of one test
-// point, OnGPIS.cpp:199).  For a matrix rhs Eigen dispatches to its blocked triangular-solve kernel,
-// which scales the pivot row by a precomputed reciprocal (a = 1/l_kk; b_k *= a) instead of dividing;
-// the vector overload above (used for alpha) divides.  Order (O1) otherwise.
-static inline void fwd_subst_rcp(const float* L, int n, int ld, float* B, int nrhs, int ldb) {
-    std::vector<float> rinv(n > 0 ? n : 1);
-    for (int k = 0; k < n; ++k) rinv[k] = 1.0f / L[k + (size_t)k * ld];
-    for (int c = 0; c < nrhs; ++c) {
-        float* b = B + (size_t)c * ldb;
-        for (int k = 0; k < n; ++k) {
-            const float* col = L + (size_t)k * ld;
-            float xk = b[k] * rinv[k];
-            b[k] = xk;
-            float nxk = -xk;
-            for (int j = k + 1; j < n; ++j) b[j] = fmaf(col[j], nxk, b[j]);
+// point, OnGPIS.cpp:199).  For a matrix rhs Eigen dispatches to its blocked triangular-solve kernel
+// (panels + GEMM updates); this restatement is the blocked algorithm GPU BLAS libraries use, with
+// 32 x 32 diagonal blocks applied through their explicit inverses:
+//     for each block c:   V_c = inv(L_cc) U_c ;   U_b -= L_bc V_c  for the rows b below.
+// inv(L_cc) (blocked_diag_inverses) is computed once per factor by forward substitution (O1) on the
+// unit vectors.  Orders: the update of a row is the ascending-k fmaf chain (O1); the product with the
+// inverse is one fmaf chain from zero over k in the order (O6)
+//     k = 0,4,1,5,2,6,3,7, 8,12,9,13,10,14,11,15, 16,... (pairs (j, j+4) inside every group of 8)
+// -- the order in which a 32x32x2 matrix instruction meets the rows of an accumulator tile.  Terms with
+// k > i vanish (the inverse is lower triangular).  Measured against an fp64 solve with the same factor
+// this is at least as accurate as plain substitution ("Numerical contract").
+static inline int o6_k(int t) { return (t & ~7) + ((t & 7) >> 1) + 4 * (t & 1); }
+// inv: [nb][32*32] row-major inverse blocks, identity-padded past n.
+static inline void blocked_diag_inverses(const float* L, int n, int ld, std::vector<float>& inv) {
+    const int nb = (n + 31) / 32;
+    inv.assign((size_t)nb * 1024, 0.f);
+    for (int c = 0; c < nb; ++c) {
+        const int r0 = 32 * c, m = (n - r0 < 32) ? n - r0 : 32;
+        float* I = &inv[(size_t)c * 1024];
+        for (int j = 0; j < 32; ++j) {
+            float e[32];
+            for (int k = 0; k < 32; ++k) e[k] = (k == j) ? 1.f : 0.f;
+            if (j < m) fwd_subst(L + r0 + (size_t)r0 * ld, m, ld, e, 1, 32);
+            for (int i = 0; i < 32; ++i) I[i * 32 + j] = e[i];
+        }
+    }
+}
+static inline void fwd_subst_blocked(const float* L, const float* inv, int n, int ld, float* B, int nrhs, int ldb) {
+    const int nb = (n + 31) / 32;
+    for (int cidx = 0; cidx < nrhs; ++cidx) {
+        float* b = B + (size_t)cidx * ldb;
+        for (int c = 0; c < nb; ++c) {
+            const int r0 = 32 * c, m = (n - r0 < 32) ? n - r0 : 32;
+            const float* I = inv + (size_t)c * 1024;
+            float u[32], v[32];
+            for (int k = 0; k < 32; ++k) u[k] = (k < m) ? b[r0 + k] : 0.f;
+            for (int i = 0; i < m; ++i) {
+                float s = 0.f;
+                for (int t = 0; t < 32; ++t) { const int k = o6_k(t); s = fmaf(I[i * 32 + k], u[k], s); }
+                v[i] = s;
+            }
+            for (int i = 0; i < m; ++i) b[r0 + i] = v[i];
+            for (int k = 0; k < m; ++k) {
+                const float* col = L + (size_t)(r0 + k) * ld;
+                const float nv = v[k];
+                for (int j = r0 + m; j < n; ++j) b[j] = fmaf(-col[j], nv, b[j]);
+            }
         }
     }
 }
