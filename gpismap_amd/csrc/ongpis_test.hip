@@ -183,6 +183,13 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                     mp = fmaf(v, s_alpha[b * 32 + rw], mp);   // rows >= K: B = 0 and alpha = 0 (K3 pads)
                 }
                 __builtin_amdgcn_wave_barrier();
+            } else if (b < nb && (A.dbg & 1024)) {   // ablation: skip the generation but keep non-trivial operand data
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    unsigned hsh = (unsigned)(lane * 2654435761u) ^ (unsigned)((b * 16 + r) * 40503u + blockIdx.x * 97u);
+                    hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+                    acc[t][r] = (float)(int)(hsh & 0xffff) * (1.0f / 65536.0f) - 0.5f;
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
