@@ -138,6 +138,72 @@ __global__ void hist_kernel(const int* __restrict__ jm, int njobs, int* __restri
     if (m >= 0) atomicAdd(&cnt[m], 1);
 }
 
+// Block-aggregated variants (model table fits in LDS): neighbouring queries mostly hit the same few
+// clusters, so counting in LDS first turns millions of same-address global atomics into one per
+// (block, cluster).  A wave whose active lanes all carry the same model adds its popcount once.
+#define BIN_CHUNK 4096   // jobs per block
+__device__ __forceinline__ void lds_count(int* sh, int m) {
+    const bool act = m >= 0;
+    const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+    if (am == 0) return;
+    const int lead = __builtin_ctzll(am);
+    const int m0 = __builtin_amdgcn_readlane(m, lead);
+    if (__builtin_amdgcn_ballot_w64(act && m == m0) == am) {
+        if ((int)(threadIdx.x & 63) == lead) atomicAdd(&sh[m0], __builtin_popcountll(am));
+    } else if (act) atomicAdd(&sh[m], 1);
+}
+__global__ __launch_bounds__(256) void hist_lds_kernel(const int* __restrict__ jm, int njobs, int nmodels,
+                                                       int* __restrict__ cnt) {
+    extern __shared__ int sh[];
+    for (int i = threadIdx.x; i < nmodels; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int j0 = blockIdx.x * BIN_CHUNK;
+    for (int k = 0; k < BIN_CHUNK; k += 256) {
+        const int j = j0 + k + threadIdx.x;
+        lds_count(sh, j < njobs ? jm[j] : -1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nmodels; i += 256) { const int c = sh[i]; if (c) atomicAdd(&cnt[i], c); }
+}
+__global__ __launch_bounds__(256) void scatter_lds_kernel(const int* __restrict__ jm, int njobs, int nmodels, int shift,
+                                                          int rec_base, const int* __restrict__ base,
+                                                          int* __restrict__ cursor, int* __restrict__ jq,
+                                                          int* __restrict__ jo) {
+    extern __shared__ int sh[];          // [nmodels] running count, [nmodels] first slot of this block
+    int* sb = sh + nmodels;
+    for (int i = threadIdx.x; i < nmodels; i += 256) sh[i] = 0;
+    __syncthreads();
+    const int j0 = blockIdx.x * BIN_CHUNK;
+    for (int k = 0; k < BIN_CHUNK; k += 256) {
+        const int j = j0 + k + threadIdx.x;
+        lds_count(sh, j < njobs ? jm[j] : -1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nmodels; i += 256) {
+        const int c = sh[i];
+        if (c) { sb[i] = base[i] + atomicAdd(&cursor[i], c); sh[i] = 0; }
+    }
+    __syncthreads();
+    for (int k = 0; k < BIN_CHUNK; k += 256) {
+        const int j = j0 + k + threadIdx.x;
+        const int m = j < njobs ? jm[j] : -1;
+        const bool act = m >= 0;
+        const unsigned long long am = __builtin_amdgcn_ballot_w64(act);
+        if (am == 0) continue;
+        const int lead = __builtin_ctzll(am);
+        const int m0 = __builtin_amdgcn_readlane(m, lead);
+        int pos = -1;
+        if (__builtin_amdgcn_ballot_w64(act && m == m0) == am) {   // one model in this wave: rank by lane
+            int first = 0;
+            if ((int)(threadIdx.x & 63) == lead) first = atomicAdd(&sh[m0], __builtin_popcountll(am));
+            first = __builtin_amdgcn_readlane(first, lead);
+            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(am >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)am, 0));
+            if (act) pos = sb[m0] + first + rank;
+        } else if (act) pos = sb[m] + atomicAdd(&sh[m], 1);
+        if (act) { jq[pos] = j >> shift; jo[pos] = rec_base + j; }
+    }
+}
+
 // single block: exclusive scan of job counts; per-class tile bases.  tot[0..3] = tiles per
 // class (tot[0..5]), tot[6] = total jobs, tot[8..13] = class tile offsets.
 __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restrict__ models, int nmodels,
@@ -393,11 +459,20 @@ int MapQuery::ensure_scratch(int n, int nmodels) {
 // Bin the jobs in d_jm_ (njobs entries) by model and run K4 over the tiles.
 int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, int nmodels, hipStream_t s) {
     GPIS_HIP(hipMemsetAsync(d_cnt_, 0, sizeof(int) * (size_t)nmodels, s));
-    hipLaunchKernelGGL(hist_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, d_cnt_);
+    const bool lds_bins = nmodels <= 8192;   // 2 x 32 KB of LDS at most
+    const int nbin_blocks = (njobs + BIN_CHUNK - 1) / BIN_CHUNK;
+    if (lds_bins)
+        hipLaunchKernelGGL(hist_lds_kernel, dim3(nbin_blocks), dim3(256), sizeof(int) * (size_t)nmodels, s, d_jm_, njobs, nmodels, d_cnt_);
+    else
+        hipLaunchKernelGGL(hist_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, d_cnt_);
     hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, store.d_models(), nmodels, d_cnt_, d_base_, d_tbase_,
                        d_cursor_, d_tot_, reinterpret_cast<unsigned long long*>(d_tot_ + 16));
-    hipLaunchKernelGGL(scatter_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, shift, rec_base, d_base_,
-                       d_cursor_, d_jq_, d_jo_);
+    if (lds_bins)
+        hipLaunchKernelGGL(scatter_lds_kernel, dim3(nbin_blocks), dim3(256), sizeof(int) * 2 * (size_t)nmodels, s, d_jm_, njobs,
+                           nmodels, shift, rec_base, d_base_, d_cursor_, d_jq_, d_jo_);
+    else
+        hipLaunchKernelGGL(scatter_kernel, dim3((njobs + 255) / 256), dim3(256), 0, s, d_jm_, njobs, shift, rec_base, d_base_,
+                           d_cursor_, d_jq_, d_jo_);
     int* t_model = d_tile_;
     int* t_off = d_tile_ + tile_cap_;
     int* t_cnt = d_tile_ + 2 * (size_t)tile_cap_;
