@@ -114,7 +114,7 @@ struct EvalArgs {
     int dbg;                 // timing ablations (env GPIS_K4_DBG; results are wrong when non-zero)
 };
 // K4 size classes by nb = ceil(K/32): 0: nb<=4 (1 wave x 4 tiles), 1: <=8 (2x4), 2: <=16 (4x4),
-// 3: <=32 (4x8), 4: <=64 (8x8), 5: <=96 (8x12); -1 -> cluster too large for this build (K > 3072)
+// 3: <=32 (8x4), 4: <=64 (16x4), 5: <=96 (8x12); -1 -> cluster too large for this build (K > 3072)
 #define ONGPIS_NCLASS 6
 __host__ __device__ inline int ongpis_class_of_nb(int nb) {
     return nb <= 4 ? 0 : (nb <= 8 ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : (nb <= 64 ? 4 : 5))));

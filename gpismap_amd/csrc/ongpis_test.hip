@@ -38,7 +38,7 @@ typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // expl
 
 
 // Size classes (block rows nb = ceil(K/32)): W waves x NBW tiles per wave.
-//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 8x4 (128 VGPRs)   <= 64: 8x8   <= 96: 8x12
+//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 8x4 (128 VGPRs)   <= 64: 16x4 (128 VGPRs)   <= 96: 8x12
 // VREG: V_c is read into registers once per step (256-VGPR classes) or streamed from LDS per MFMA pair
 // (128-VGPR classes, four waves per SIMD).  TR: cycle-trace build of the kernel (GPIS_K4_TRACE).
 template <int W, int NBW, int MINW, bool VREG, bool TR>
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 }
 
 // Size classes by nb = ceil(K/32): W waves x NBW tiles per wave (ongpis.h, ongpis_class_of_nb).
-static const int kClassW[6] = {1, 2, 4, 8, 8, 8};
+static const int kClassW[6] = {1, 2, 4, 8, 16, 8};
 static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
 
 static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
@@ -398,7 +398,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     static const kern_t kern[ONGPIS_NCLASS] = {
         ongpis_eval_kernel<1, 4, 2, true, false>, ongpis_eval_kernel<2, 4, 2, true, false>,
         ongpis_eval_kernel<4, 4, 2, true, false>, ongpis_eval_kernel<8, 4, 4, false, false>,
-        ongpis_eval_kernel<8, 8, 2, true, false>, ongpis_eval_kernel<8, 12, 2, true, false>};
+        ongpis_eval_kernel<16, 4, 4, false, false>, ongpis_eval_kernel<8, 12, 2, true, false>};
     static const kern_t kern_tr = ongpis_eval_kernel<8, 4, 4, false, true>;   // traced build of class 3
     static bool attr_set = false;
     if (!attr_set) {

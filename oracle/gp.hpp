@@ -421,11 +421,11 @@ struct OnGPIS {
     // with packet-wise interleaved partial sums (order unspecified); this restatement fixes
     // 2*W interleaved partial chains: row r goes to chain (w, h) with w = (r / 32) mod W,
     // h = (r / 4) mod 2, each chain is an ascending fmaf chain, the pair (w,0)+(w,1) is added,
-    // and the W pair sums are accumulated in ascending w.  W = 1, 2, 4, 8 for K <= 128, 256, 512
-    // and above.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
+    // and the W pair sums are accumulated in ascending w.  W = 1, 2, 4, 8, 16 for K <= 128, 256, 512,
+    // 1024, 2048 and 8 above.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
     static int chains_W(int K) {
         int nb = (K + 31) / 32;
-        return nb <= 4 ? 1 : (nb <= 8 ? 2 : (nb <= 16 ? 4 : 8));
+        return nb <= 4 ? 1 : (nb <= 8 ? 2 : (nb <= 16 ? 4 : (nb <= 32 ? 8 : (nb <= 64 ? 16 : 8))));
     }
     template <class F>
     static float reduce_O3(int K, F&& term_chain) {
