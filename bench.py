@@ -141,6 +141,13 @@ def main():
         n_pts = n_total * args.steps
         value = n_pts / elapsed
         tflops = (flops / 1e12) / (k4_ms / 1e3) if k4_ms > 0 else None
+        # HBM bytes per K4 launch: measured with rocprofv3 PMC counters in separate passes of this command
+        # (profiles/README.md); a committed measurement, not collected live
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k4_traffic.json")
+        if os.path.exists(tpath) and args.grid == 256 and args.frames == 2:
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("hbm_bytes_per_launch")
         out = {
             "metric": "sdf_test_points_per_sec",
             "value": value,
@@ -163,7 +170,7 @@ def main():
             "update_ms_frames": upd_ms,
             "gp_evals_per_point": evals / (hi - lo) / args.steps,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
-                         "frac": (tflops / 157.3) if tflops else None, "traffic": None,
+                         "frac": (tflops / 157.3) if tflops else None, "traffic": traffic,
                          "kernel": "ongpis_eval_kernel (K4)", "k4_ms_per_step": k4_ms / args.steps,
                          "k4_launches_per_step": launches / args.steps,
                          "algorithmic_flops_per_step": flops / args.steps,
