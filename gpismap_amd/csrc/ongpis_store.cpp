@@ -120,6 +120,14 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
         }
         int rc = alloc_model(tj.model, tj.n, tj.ng);
         if (rc) return rc;
+    }
+    // largest clusters first: one workgroup per cluster and K^3 work, so the big factorisations must not start last
+    std::vector<int> ord(nj);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) {
+        return jobs[a].n + dim_ * jobs[a].ng > jobs[b].n + dim_ * jobs[b].ng; });
+    for (int j = 0; j < nj; ++j) {
+        const TrainJob& tj = jobs[ord[j]];
         tab[4 * j] = tj.model; tab[4 * j + 1] = tj.off; tab[4 * j + 2] = tj.n; tab[4 * j + 3] = tj.ng;
     }
     int rc = sync_models(s);
