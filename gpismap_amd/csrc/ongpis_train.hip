@@ -214,32 +214,37 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                 }
             }
             if (act[0]) {
+                // panel operands: a_ = +L(j, p) double-buffered over p, bq = -L(bi, p) double-buffered over the
+                // sequence of tile products (2 NT per loop trip, so the buffer index of every product is static)
                 float a_[2][16];
-                if (j > 0) load_tile(a_[0], j, 0, 0x80000000u);   // a_ = +L(j, p)
+                float bq[2][16];
+                auto issue_b = [&](float (&dst)[16], int tt, int p) {
+                    if (act[tt] && p < j) load_tile(dst, j + wave + NW * (t0 + tt), p, 0u);
+                };
+                if (j > 0) { load_tile(a_[0], j, 0, 0x80000000u); issue_b(bq[0], 0, 0); }
 #pragma unroll 1
                 for (int p = 0; p < j; p += 2) {
-                    // two panels per iteration so the double buffer index stays static
                     if (p + 1 < j) load_tile(a_[1], j, p + 1, 0x80000000u);
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
+                        const int k = tt;
+                        if (tt + 1 < NT) issue_b(bq[(k + 1) & 1], tt + 1, p); else issue_b(bq[(k + 1) & 1], 0, p + 1);
                         if (act[tt]) {
-                            float b_[16];
-                            load_tile(b_, j + wave + NW * (t0 + tt), p, 0u);   // b_ = -L(bi, p)
 #pragma unroll
                             for (int kk = 0; kk < 16; ++kk)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0][kk], b_[kk], acc[tt], 0, 0, 0);
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
                         }
                     }
                     if (p + 1 < j) {
                         if (p + 2 < j) load_tile(a_[0], j, p + 2, 0x80000000u);
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) {
+                            const int k = NT + tt;
+                            if (tt + 1 < NT) issue_b(bq[(k + 1) & 1], tt + 1, p + 1); else issue_b(bq[(k + 1) & 1], 0, p + 2);
                             if (act[tt]) {
-                                float b_[16];
-                                load_tile(b_, j + wave + NW * (t0 + tt), p + 1, 0u);
 #pragma unroll
                                 for (int kk = 0; kk < 16; ++kk)
-                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1][kk], b_[kk], acc[tt], 0, 0, 0);
+                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
                             }
                         }
                     }
@@ -252,28 +257,62 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                     for (int r = 0; r < 16; ++r) D[l31 * 33 + rowmap_t(r, h)] = acc[0][r];
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
-                    volatile float* Dv = D;
-                    for (int c = 0; c < pw; ++c) {
-                        float d = sqrtf(Dv[c * 33 + c]);
-                        float lij = 0.f;
-                        const bool below = (lane > c && lane < 32);
-                        if (below) lij = Dv[lane * 33 + c] / d;
-                        if (lane == c) Dv[c * 33 + c] = d;
-                        if (below) Dv[lane * 33 + c] = lij;
-                        if (below) {
-                            const float nl = -lij;
-                            const int kend = min(lane, pw - 1);
-                            for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    // column-major copy for the solves, and the factor itself to global memory (lower part)
-                    // (identity-padded past the last row of a partial block: the padding rows of K4's solve stay zero)
-                    if (lane < 32) {
+                    if (pw == 32) {
+                        // Full block: right-looking factorisation in registers.  lane = row (both lane halves carry
+                        // the same rows), a[k] = column k; pivots and column entries travel by v_readlane.  Element
+                        // (i, k) takes fmaf(-l_ic, l_kc, .) for c ascending: order (O1).  Entries above the diagonal
+                        // are scratch values nobody reads.
+                        const int row = lane & 31;
+                        float a[32];
+#pragma unroll
+                        for (int k = 0; k < 32; ++k) a[k] = D[row * 33 + k];
+#pragma unroll
                         for (int c = 0; c < 32; ++c) {
-                            float v = Dv[lane * 33 + c];
-                            Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
-                            if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                            const float piv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), c));
+                            const float d = sqrtf(piv);
+                            const float lic = a[c] / d;
+                            a[c] = (row == c) ? d : lic;
+                            const float nl = -lic;
+#pragma unroll
+                            for (int k = c + 1; k < 32; ++k) {
+                                const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), k));
+                                a[k] = fmaf(nl, lkc, a[k]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);   // keep the broadcast values of one column step together
+                        }
+                        // column-major copy for the solves, and the factor itself to global memory (lower part)
+                        if (lane < 32) {
+#pragma unroll
+                            for (int c = 0; c < 32; ++c) {
+                                Lc[c * 32 + lane] = a[c];
+                                if (c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = a[c];
+                            }
+                        }
+                    } else {
+                        // Partial last block (once per cluster): same operations through LDS; rows >= pw (the y row K
+                        // and the padding) are carried along as rows of the matrix.
+                        volatile float* Dv = D;
+                        for (int c = 0; c < pw; ++c) {
+                            float d = sqrtf(Dv[c * 33 + c]);
+                            float lij = 0.f;
+                            const bool below = (lane > c && lane < 32);
+                            if (below) lij = Dv[lane * 33 + c] / d;
+                            if (lane == c) Dv[c * 33 + c] = d;
+                            if (below) Dv[lane * 33 + c] = lij;
+                            if (below) {
+                                const float nl = -lij;
+                                const int kend = min(lane, pw - 1);
+                                for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
+                            }
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                        // (identity-padded past the last row: the padding rows of K4's solve stay zero)
+                        if (lane < 32) {
+                            for (int c = 0; c < 32; ++c) {
+                                float v = Dv[lane * 33 + c];
+                                Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
+                                if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                            }
                         }
                     }
                 }
