@@ -233,7 +233,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             Vw[((r & 3) + 8 * (r >> 2)) * 32] = v[r];
             ss = fmaf(v[r], v[r], ss);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS only: global loads in flight need not drain
         if (lane == 0) *pub = c;
         TRACE_OWN();   // published
     };
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             TRACE();
             while (*pub < c) __builtin_amdgcn_s_sleep(1);
             TRACE();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
             const float* Vb = Vbuf + (c % RING) * 1024 + (h * 32 + l31);   // B operand kk: Vb[64 kk]
             if (owner) {
                 __builtin_amdgcn_s_setprio(3);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             TRACE();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS only: global loads in flight need not drain
             if (lane == 0) done[wave] = c;
         }
     }
