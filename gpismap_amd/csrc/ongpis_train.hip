@@ -172,7 +172,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
     __shared__ __attribute__((aligned(16))) float Tt[8][32 * 36];   // per-wave tile transpose buffer
     __shared__ float av[32];
     const int job = blockIdx.x, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile offsets stay scalar (no waterfall loops around the buffer loads)
     const int h = lane >> 5, l31 = lane & 31;
     constexpr int NW = 8;
     const ClusterModel m = models[JOB_MODEL(job)];
@@ -214,17 +215,18 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                 }
             }
             if (act[0]) {
-                // panel operands: a_ = +L(j, p) double-buffered over p, bq = -L(bi, p) double-buffered over the
+                // panel operands: a_ = -L(j, p) (sign flipped at the matrix instruction: flipping at the load would make
+                // every load wait for its data) double-buffered over p, bq = -L(bi, p) double-buffered over the
                 // sequence of tile products (2 NT per loop trip, so the buffer index of every product is static)
                 float a_[2][16];
                 float bq[2][16];
                 auto issue_b = [&](float (&dst)[16], int tt, int p) {
                     if (act[tt] && p < j) load_tile(dst, j + wave + NW * (t0 + tt), p, 0u);
                 };
-                if (j > 0) { load_tile(a_[0], j, 0, 0x80000000u); issue_b(bq[0], 0, 0); }
+                if (j > 0) { load_tile(a_[0], j, 0, 0u); issue_b(bq[0], 0, 0); }
 #pragma unroll 1
                 for (int p = 0; p < j; p += 2) {
-                    if (p + 1 < j) load_tile(a_[1], j, p + 1, 0x80000000u);
+                    if (p + 1 < j) load_tile(a_[1], j, p + 1, 0u);
 #pragma unroll
                     for (int tt = 0; tt < NT; ++tt) {
                         const int k = tt;
@@ -232,11 +234,11 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                         if (act[tt]) {
 #pragma unroll
                             for (int kk = 0; kk < 16; ++kk)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
+                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
                         }
                     }
                     if (p + 1 < j) {
-                        if (p + 2 < j) load_tile(a_[0], j, p + 2, 0x80000000u);
+                        if (p + 2 < j) load_tile(a_[0], j, p + 2, 0u);
 #pragma unroll
                         for (int tt = 0; tt < NT; ++tt) {
                             const int k = NT + tt;
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                             if (act[tt]) {
 #pragma unroll
                                 for (int kk = 0; kk < 16; ++kk)
-                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
+                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
                             }
                         }
                     }
