@@ -111,7 +111,7 @@ def main():
 
     # ---- CPU baseline: the oracle on the host cores, bounded subsample of the same grid ----
     cpu = None
-    if rank == 0 and args.cpu_sample > 0:
+    if rank == 0 and world == 1 and args.cpu_sample > 0:   # N = 1 only (bench contract)
         import oracle_lib
         om = oracle_lib.OracleMap3()
         t0 = time.perf_counter()
