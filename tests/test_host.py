@@ -131,3 +131,31 @@ def test_slab_gather_world2_gloo():
         p.join(timeout=60)
     assert all(r[1] for r in res), res
     assert res[0][2] == (0, 501) and res[1][2] == (501, 1003)
+
+
+def _build_dropin(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "dropin_demo")
+    libdir = os.path.join(ROOT, "gpismap_amd")
+    cmd = ["g++", "-std=c++11", "-pthread", "-fPIC", "-O1", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cpp", "dropin_demo.cpp"), "-L" + libdir, "-lgpismap_amd",
+           "-Wl,-rpath," + libdir, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def test_cpp_surface_builds_with_the_gateway_flags(tmp_path):
+    """include/GPisMap3.h and include/GPisMap.h used the way mexGPisMap3.cpp / mexGPisMap.cpp use the
+    reference classes, compiled with the gateways' own flags (-std=c++11 -pthread -fPIC) and linked against
+    the library.  Without a GPU the objects construct, refuse to work loudly and return false -- no fallback."""
+    import subprocess
+    exe = _build_dropin(tmp_path)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    assert "map_dimension 2" in r.stdout
+    assert "test_before_update 0" in r.stdout and "test_wrong_dim 0" in r.stdout
+    import gpismap_amd
+    if gpismap_amd.device_count() < 1:
+        assert "map3 ok 0" in r.stdout and "map2 ok 0" in r.stdout
+        assert "HIP device unavailable" in r.stderr
