@@ -394,6 +394,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
     if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
     if (lds > budget) return GPIS_ERR_LIMIT;
+    if (args.use_table && getenv("GPIS_K4_NOTABLE")) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }   // test hook: exercise the large-cluster path
     typedef void (*kern_t)(EvalArgs);
     static const kern_t kern[ONGPIS_NCLASS] = {
         ongpis_eval_kernel<1, 4, 2, true, false>, ongpis_eval_kernel<2, 4, 2, true, false>,

@@ -105,6 +105,32 @@ def test_train_and_predict_match_oracle(dim, scale, sizes):
     assert d_vg < 1e-4         # relative to the prior 3/s^2
 
 
+def test_predict_without_exp_table_is_identical(monkeypatch):
+    """Clusters too large for the per-tile exp table in LDS take a path that evaluates exp() per kernel
+    entry (GPIS_K4_NOTABLE forces it): results must not change by a bit."""
+    import gpismap_amd
+    dim, scale = 3, 0.04
+    rng = np.random.default_rng(77)
+    sizes = [30, 130, 260]
+    clusters = [make_cluster(rng, dim, n, scale) for n in sizes]
+    pos = np.concatenate([c[0] for c in clusters]); grad = np.concatenate([c[1] for c in clusters])
+    val = np.concatenate([c[2] for c in clusters]); sx = np.concatenate([c[3] for c in clusters])
+    sg = np.concatenate([c[4] for c in clusters])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ids = np.arange(off[-1], dtype=np.int32)
+    st = gpismap_amd.OnGPIS(dim, scale)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), off, ids)
+    nq = 41
+    xq = np.concatenate([pos[off[i]:off[i + 1]][rng.integers(0, sizes[i], nq)] + rng.normal(0, 0.3 * scale, (nq, dim))
+                         for i in range(len(sizes))]).astype(np.float32)
+    jq = np.arange(xq.shape[0], dtype=np.int32)
+    jm = np.repeat(models, nq).astype(np.int32)
+    with_table = st.eval(xq, jq, jm).copy()
+    monkeypatch.setenv("GPIS_K4_NOTABLE", "1")
+    without = st.eval(xq, jq, jm)
+    assert np.array_equal(with_table.view(np.uint32), without.view(np.uint32))
+
+
 def test_oversize_cluster_is_refused():
     import gpismap_amd
     rng = np.random.default_rng(3)
