@@ -215,38 +215,35 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
                 }
             }
             if (act[0]) {
-                // panel operands: a_ = -L(j, p) (sign flipped at the matrix instruction: flipping at the load would make
-                // every load wait for its data) double-buffered over p, bq = -L(bi, p) double-buffered over the
-                // sequence of tile products (2 NT per loop trip, so the buffer index of every product is static)
-                float a_[2][16];
-                float bq[2][16];
-                auto issue_b = [&](float (&dst)[16], int tt, int p) {
-                    if (act[tt] && p < j) load_tile(dst, j + wave + NW * (t0 + tt), p, 0u);
-                };
-                if (j > 0) { load_tile(a_[0], j, 0, 0u); issue_b(bq[0], 0, 0); }
+                // Panel operands: a_ = -L(j, p) (sign flipped at the matrix instruction), bq = -L(bi, p).  The
+                // panel loop is blocked by PB: every load of a trip is issued AND consumed inside it (fully
+                // unrolled, so the buffers alternate statically and the waits are partial) -- loads carried
+                // across the loop back-edge would make the compiler drain the queue at the top of each trip.
+                constexpr int PB = 4;
 #pragma unroll 1
-                for (int p = 0; p < j; p += 2) {
-                    if (p + 1 < j) load_tile(a_[1], j, p + 1, 0u);
+                for (int p0 = 0; p0 < j; p0 += PB) {
+                    float a_[2][16];
+                    float bq[2][16];
+                    auto issue_b = [&](float (&dst)[16], int tt, int p) {
+                        if (act[tt] && p < j) load_tile(dst, j + wave + NW * (t0 + tt), p, 0u);
+                    };
+                    load_tile(a_[0], j, p0, 0u);
+                    issue_b(bq[0], 0, p0);
 #pragma unroll
-                    for (int tt = 0; tt < NT; ++tt) {
-                        const int k = tt;
-                        if (tt + 1 < NT) issue_b(bq[(k + 1) & 1], tt + 1, p); else issue_b(bq[(k + 1) & 1], 0, p + 1);
-                        if (act[tt]) {
+                    for (int i = 0; i < PB; ++i) {
+                        const int p = p0 + i;
+                        if (p < j) {
+                            if (i + 1 < PB && p + 1 < j) load_tile(a_[(i + 1) & 1], j, p + 1, 0u);
 #pragma unroll
-                            for (int kk = 0; kk < 16; ++kk)
-                                acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
-                        }
-                    }
-                    if (p + 1 < j) {
-                        if (p + 2 < j) load_tile(a_[0], j, p + 2, 0u);
+                            for (int tt = 0; tt < NT; ++tt) {
+                                const int k = i * NT + tt;
+                                if (tt + 1 < NT) issue_b(bq[(k + 1) & 1], tt + 1, p);
+                                else if (i + 1 < PB) issue_b(bq[(k + 1) & 1], 0, p + 1);
+                                if (act[tt]) {
 #pragma unroll
-                        for (int tt = 0; tt < NT; ++tt) {
-                            const int k = NT + tt;
-                            if (tt + 1 < NT) issue_b(bq[(k + 1) & 1], tt + 1, p + 1); else issue_b(bq[(k + 1) & 1], 0, p + 2);
-                            if (act[tt]) {
-#pragma unroll
-                                for (int kk = 0; kk < 16; ++kk)
-                                    acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
+                                    for (int kk = 0; kk < 16; ++kk)
+                                        acc[tt] = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[i & 1][kk], bq[k & 1][kk], acc[tt], 0, 0, 0);
+                                }
                             }
                         }
                     }
