@@ -53,54 +53,4 @@ __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) 
     }
 }
 
-// K4's variant.  Ls = diagonal tile in "solve layout" (ongpis.h: -L strictly below the diagonal, zero on
-// and above it, column-major in LDS), rl = 1 / L_kk for k = lane & 31.  The pivot row is scaled by the
-// reciprocal (what Eigen does for a matrix right-hand side, OnGPIS.cpp:199) and, because the tile is zero on and
-// above the diagonal, every later register simply takes fma(-l, v_i, .) -- two rows per v_pk_fma_f32, no
-// per-row selects: rows <= i see l = 0 and keep their value.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <bool PIPE, class Probe>
-__device__ __forceinline__ void diag_solve32_rcp(f32x16& v, const float* Ls, float rl, int h, Probe&& probe) {
-    const float4* base = reinterpret_cast<const float4*>(Ls) + h;   // column i, rows 8g+4h..+3: base[8 i + 2 g]
-    float4 cur[4], nxt[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) cur[g] = base[2 * g];
-#pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        if (PIPE && i + 1 < 32) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (8 * g + 7 > i + 1) nxt[g] = base[8 * (i + 1) + 2 * g];
-        }
-        if ((i & 7) == 0) probe();   // cycle-trace hook of the traced K4 build (empty otherwise)
-        const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
-        const float rinv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(rl), i));
-        const float cand = v[ri] * rinv;
-        const unsigned cu = __float_as_uint(cand);
-        auto sw = __builtin_amdgcn_permlane32_swap(cu, cu, false, false);
-        const float vi = __uint_as_float(hi_ ? sw[1] : sw[0]);
-        const f32x2 vv = {vi, vi};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            if (8 * g + 7 > i) {
-                f32x2 a = {v[4 * g], v[4 * g + 1]}, b = {v[4 * g + 2], v[4 * g + 3]};
-                const f32x2 l0 = {cur[g].x, cur[g].y}, l1 = {cur[g].z, cur[g].w};
-                a = __builtin_elementwise_fma(l0, vv, a);
-                b = __builtin_elementwise_fma(l1, vv, b);
-                v[4 * g] = a.x; v[4 * g + 1] = a.y; v[4 * g + 2] = b.x; v[4 * g + 3] = b.y;
-            }
-        }
-        v[ri] = (h == hi_) ? vi : v[ri];
-        if (PIPE) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) cur[g] = nxt[g];
-        } else if (i + 1 < 32) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-                if (8 * g + 7 > i + 1) cur[g] = base[8 * (i + 1) + 2 * g];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 }  // namespace gpis
