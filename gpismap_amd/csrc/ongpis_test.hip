@@ -134,67 +134,100 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
             const int q = 4 * qh + j;
             xqs[j] = (q < jcnt) ? A.xq[A.job_q[joff + q]] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
+        // The 16 entries of one (row, 4 queries) strip.  KIND = row type of the whole tile when it is uniform
+        // (0: value rows, 1..3: d/dx_c rows -- the rows are ordered by type, so almost every tile is uniform and
+        // the compiler folds the type selects of covFnc.cpp:292-308 away), -1: mixed tile, per-row type.
+        auto emit_rows = [&](auto kind_tag, int b) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            const int row = b * 32 + rr_;
+            float4 out[4];
 #pragma unroll
-        for (int t = 0; t < NBW; ++t) {
-            const int b = wave + W * t;
-            if (b < nb && !(A.dbg & 1)) {
-                const int row = b * 32 + rr_;
-                float4 out[4];
+            for (int j = 0; j < 4; ++j) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < K) {
+                const int info = s_ri[row];
+                const int p = info & 0x0FFFFFFF;
+                const int cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
+                const float4 xp = x4[p];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < K) {
-                    const int info = s_ri[row];
-                    const int p = info & 0x0FFFFFFF, cr = (info >> 28) & 0xF;
-                    const float4 xp = x4[p];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int q = 4 * qh + j;
-                        if (q < jcnt) {
-                            float d[3] = {xp.x - xqs[j].x, xp.y - xqs[j].y, xp.z - xqs[j].z};
-                            float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
-                            double e = A.use_table ? etab[p * 8 + q] : exp((double)(-a * rr));
-                            float v0, v1, v2, v3;
-                            if (cr == 0) {
-                                v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
-                            } else {
-                                const float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
-                                v0 = -d_kf1(dr, a, e);
-                                // mixed second derivatives: lower component first (covFnc.cpp:300-308)
-                                v1 = (cr == 1) ? d_kf2(rr, d[0], d[0], 1.0f, a, e) : d_kf2(rr, d[0], dr, 0.0f, a, e);
-                                v2 = (cr == 2) ? d_kf2(rr, d[1], d[1], 1.0f, a, e)
-                                               : (cr == 1 ? d_kf2(rr, d[0], d[1], 0.0f, a, e) : d_kf2(rr, d[1], d[2], 0.0f, a, e));
-                                v3 = (cr == 3) ? d_kf2(rr, d[2], d[2], 1.0f, a, e) : d_kf2(rr, dr, d[2], 0.0f, a, e);
-                            }
-                            if (dim == 2) v3 = 0.f;
-                            out[j] = make_float4(v0, v1, v2, v3);
+                for (int j = 0; j < 4; ++j) {
+                    const int q = 4 * qh + j;
+                    if (q < jcnt) {
+                        float d[3] = {xp.x - xqs[j].x, xp.y - xqs[j].y, xp.z - xqs[j].z};
+                        float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
+                        double e = A.use_table ? etab[p * 8 + q] : exp((double)(-a * rr));
+                        float v0, v1, v2, v3;
+                        if (cr == 0) {
+                            v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
+                        } else {
+                            const float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
+                            v0 = -d_kf1(dr, a, e);
+                            // mixed second derivatives: lower component first (covFnc.cpp:300-308)
+                            v1 = (cr == 1) ? d_kf2(rr, d[0], d[0], 1.0f, a, e) : d_kf2(rr, d[0], dr, 0.0f, a, e);
+                            v2 = (cr == 2) ? d_kf2(rr, d[1], d[1], 1.0f, a, e)
+                                           : (cr == 1 ? d_kf2(rr, d[0], d[1], 0.0f, a, e) : d_kf2(rr, d[1], d[2], 0.0f, a, e));
+                            v3 = (cr == 3) ? d_kf2(rr, d[2], d[2], 1.0f, a, e) : d_kf2(rr, dr, d[2], 0.0f, a, e);
                         }
+                        if (dim == 2) v3 = 0.f;
+                        out[j] = make_float4(v0, v1, v2, v3);
                     }
                 }
-                float4* trow = reinterpret_cast<float4*>(tbuf + rr_ * 36 + 16 * qh);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) trow[j] = out[j];
-                __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int rw = rowmap_t(r, h);
-                    const float v = tbuf[rw * 36 + l31];
-                    acc[t][r] = v;
-                    mp = fmaf(v, s_alpha[b * 32 + rw], mp);   // rows >= K: B = 0 and alpha = 0 (K3 pads)
-                }
-                __builtin_amdgcn_wave_barrier();
-            } else if (b < nb && (A.dbg & 1024)) {   // ablation: skip the generation but keep non-trivial operand data
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    unsigned hsh = (unsigned)(lane * 2654435761u) ^ (unsigned)((b * 16 + r) * 40503u + blockIdx.x * 97u);
-                    hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
-                    acc[t][r] = (float)(int)(hsh & 0xffff) * (1.0f / 65536.0f) - 0.5f;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
             }
-            __builtin_amdgcn_sched_barrier(0);
+            float4* trow = reinterpret_cast<float4*>(tbuf + rr_ * 36 + 16 * qh);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) trow[j] = out[j];
+        };
+        // padded LDS strip -> accumulator tile t (static register index) + partial means
+        auto take_tile = [&](f32x16& tl, int b) {
+            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rw = rowmap_t(r, h);
+                const float v = tbuf[rw * 36 + l31];
+                tl[r] = v;
+                mp = fmaf(v, s_alpha[b * 32 + rw], mp);   // rows >= K: B = 0 and alpha = 0 (K3 pads)
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        const int ngr = (dim > 0) ? (K - N) / dim : 0;   // rows per derivative component
+        auto row_type = [&](int r) { return r < N ? 0 : 1 + (r - N) / (ngr > 0 ? ngr : 1); };
+#pragma unroll
+        for (int t = 0; t < NBW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll 1
+        for (int t = 0; t < NBW; ++t) {
+            // The evaluation code exists once: every tile is generated into the LAST register tile after a rotation
+            // by one place; after NBW trips each tile sits in its home position.
+            {
+                const f32x16 t0 = acc[0];
+#pragma unroll
+                for (int u = 0; u + 1 < NBW; ++u) acc[u] = acc[u + 1];
+                acc[NBW - 1] = t0;
+            }
+            const int b = wave + W * t;
+            if (b < nb && !(A.dbg & 1)) {
+                const int r0 = b * 32, r1 = min(K, r0 + 32) - 1;
+                const int k0 = row_type(r0), k1 = row_type(r1);
+                if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), b);
+                else if (k0 == 0) emit_rows(std::integral_constant<int, 0>(), b);
+                else if (k0 == 1) emit_rows(std::integral_constant<int, 1>(), b);
+                else if (k0 == 2) emit_rows(std::integral_constant<int, 2>(), b);
+                else emit_rows(std::integral_constant<int, 3>(), b);
+                take_tile(acc[NBW - 1], b);
+            }
+        }
+        if (A.dbg & 1024) {   // ablation (with dbg & 1): skip the generation but keep non-trivial operand data
+#pragma unroll
+            for (int t = 0; t < NBW; ++t)
+                if (wave + W * t < nb) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        unsigned hsh = (unsigned)(lane * 2654435761u) ^ (unsigned)(((wave + W * t) * 16 + r) * 40503u + blockIdx.x * 97u);
+                        hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
+                        acc[t][r] = (float)(int)(hsh & 0xffff) * (1.0f / 65536.0f) - 0.5f;
+                    }
+                }
         }
     }
 
