@@ -115,6 +115,12 @@ int orc2_obsgp_sizes(void* h, int* out, int cap) {
 // ---- component level -------------------------------------------------------
 void orc_chol_lower(float* A, int n, int ld) { chol_lower(A, n, ld); }
 void orc_fwd_subst(const float* L, int n, int ld, float* B, int nrhs, int ldb) { fwd_subst(L, n, ld, B, nrhs, ldb); }
+// the matrix-rhs variant used by the prediction (blocked, inverted 32x32 diagonal blocks; linalg.hpp)
+void orc_fwd_subst_blocked(const float* L, int n, int ld, float* B, int nrhs, int ldb) {
+    std::vector<float> inv;
+    blocked_diag_inverses(L, n, ld, inv);
+    fwd_subst_blocked(L, inv.data(), n, ld, B, nrhs, ldb);
+}
 void orc_bwd_subst(const float* L, int n, int ld, float* b) { bwd_subst(L, n, ld, b); }
 
 // OU GP on one group (dim x n, n <= 64): outputs L (n x n col-major, lower) and alpha.

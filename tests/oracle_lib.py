@@ -59,6 +59,7 @@ def lib():
         L.orc2_obsgp_sizes.argtypes = [C.c_void_p, ip, C.c_int]
         L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
         L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
+        L.orc_fwd_subst_blocked.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.orc_bwd_subst.argtypes = [fp, C.c_int, C.c_int, fp]
         L.orc_gpou_train.argtypes = [fp, fp, C.c_int, C.c_int, fp, fp]
         L.orc_gpou_test.argtypes = [fp, fp, C.c_int, C.c_int, fp, C.c_int, fp, fp]

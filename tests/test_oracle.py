@@ -37,6 +37,30 @@ def test_chol_and_substitutions_against_float64():
         assert np.abs(y - np.linalg.solve(np.tril(ref).T, b)).max() < 1e-4 * (1 + np.abs(y).max())
 
 
+def test_blocked_matrix_solve_is_equivalent_to_substitution():
+    """The prediction solves L V = k* with the blocked algorithm (inverted 32x32 diagonal blocks, order O6).
+    Against an fp64 solve with the same fp32 factor it must be as good as plain fp32 substitution (O1), on
+    trained cluster factors of every size class; the two fp32 results agree to fp32 round-off."""
+    from scipy.linalg import solve_triangular
+    L_ = oracle_lib.lib()
+    rng = np.random.default_rng(21)
+    for dim, scale, n in ((3, 0.04, 40), (3, 0.04, 130), (3, 0.04, 330), (2, 1.2, 150)):
+        pos, grad, val, sx, sg = make_cluster(rng, dim, n, scale)
+        tr = oracle_lib.ongpis_train(dim, scale, pos, grad, val, sx, sg)
+        K, Lm = tr["K"], tr["L"]
+        B = rng.normal(size=(K, 8)).astype(np.float32) * np.exp(-rng.uniform(0, 6, (K, 1))).astype(np.float32)
+        flat = np.ascontiguousarray(Lm.T).reshape(-1)          # column-major
+        ref = solve_triangular(Lm.astype(np.float64), B.astype(np.float64), lower=True)
+        plain = np.ascontiguousarray(B.T).copy(); blocked = plain.copy()
+        L_.orc_fwd_subst(oracle_lib._p(flat), K, K, oracle_lib._p(plain), 8, K)
+        L_.orc_fwd_subst_blocked(oracle_lib._p(flat), K, K, oracle_lib._p(blocked), 8, K)
+        e_plain = np.abs(plain.T - ref).max() / np.abs(ref).max()
+        e_blocked = np.abs(blocked.T - ref).max() / np.abs(ref).max()
+        print("K=%d: rel err vs fp64  substitution %.2e  blocked %.2e" % (K, e_plain, e_blocked))
+        assert e_blocked < 1e-5 and e_blocked < 2 * e_plain + 1e-7
+        assert np.abs(blocked - plain).max() / np.abs(ref).max() < 1e-5
+
+
 def test_gpou_against_arbiter():
     rng = np.random.default_rng(1)
     L_ = oracle_lib.lib()
