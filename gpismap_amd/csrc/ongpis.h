@@ -96,7 +96,7 @@ private:
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
-void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
+void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int small, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;

@@ -152,7 +152,12 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     }
     ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
     ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
-    ongpis_launch_chol(d_models_, d_jobs_, nj, s);   // also produces the re-tiled copy Lt
+    // Factorisation (also produces the re-tiled copy Lt).  The table is sorted by size: the tail of small
+    // clusters (K <= 256) goes to 4-wave workgroups, two per CU.
+    int nbig = 0;
+    while (nbig < nj && tab[4 * nbig + 2] + dim_ * tab[4 * nbig + 3] > 256) ++nbig;
+    if (nbig > 0) ongpis_launch_chol(d_models_, d_jobs_, nbig, 0, s);
+    if (nbig < nj) ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbig, nj - nbig, 1, s);
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 }
 
 // ---------------------------------------------------------------------------
-// K3.  grid = jobs, block = 512 (8 waves), two workgroups per CU.
+// K3.  grid = jobs, block = 64 NW: 8 waves, or 4 for launches of small clusters (K <= 256).
 // Left-looking 32-blocked Cholesky of rows 0..K (row K = y) with the tiles of the current block
 // column resident in MFMA accumulators:
 //   tile(bi, j) = A(bi, j) - sum_{p<j} L(bi, p) L(j, p)^T      v_mfma_f32_32x32x2_f32, ascending p and k
@@ -164,18 +164,17 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 + c; }
 
-template <int NT>
-__global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
+template <int NT, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
                                                               const int* __restrict__ d_jobs) {
     __shared__ __attribute__((aligned(16))) float D[32 * 33];       // diagonal tile, row-major padded (factor workspace)
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];      // factored diagonal tile, column-major (for the solves)
-    __shared__ __attribute__((aligned(16))) float Tt[8][32 * 36];   // per-wave tile transpose buffer
+    __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];  // per-wave tile transpose buffer
     __shared__ float av[32];
     const int job = blockIdx.x, tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile offsets stay scalar (no waterfall loops around the buffer loads)
     const int h = lane >> 5, l31 = lane & 31;
-    constexpr int NW = 8;
     const ClusterModel m = models[JOB_MODEL(job)];
     const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
@@ -364,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
     }
 
     // z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2)
-    for (int jj = tid; jj < K; jj += 512) m.y[jj] = L[K + (size_t)jj * ld];
+    for (int jj = tid; jj < K; jj += 64 * NW) m.y[jj] = L[K + (size_t)jj * ld];
     __syncthreads();
     for (int c = nb - 1; c >= 0; --c) {
         const int cr = 32 * c;
@@ -388,7 +387,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
             }
         }
         __syncthreads();
-        for (int jj = tid; jj < cr; jj += 512) {
+        for (int jj = tid; jj < cr; jj += 64 * NW) {
             float s = m.y[jj];
             const float* col = L + (size_t)cr + (size_t)jj * ld;
             for (int k = 31; k >= 0; --k)
@@ -398,14 +397,14 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_kernel(const ClusterModel*
         __syncthreads();
     }
     // restore the identity in row K so the padded square is a valid triangular factor
-    for (int jj = tid; jj < K; jj += 512) L[K + (size_t)jj * ld] = 0.f;
+    for (int jj = tid; jj < K; jj += 64 * NW) L[K + (size_t)jj * ld] = 0.f;
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
     // K4 runs over whole 32-row blocks without row predicates: the padding rows K..32nb-1 must stay exactly
     // zero through its solve, so alpha is zero there and row K (the y row) is cleared in the re-tiled copy too.
-    for (int jj = K + tid; jj < ld; jj += 512) m.alpha[jj] = 0.f;
+    for (int jj = K + tid; jj < ld; jj += 64 * NW) m.alpha[jj] = 0.f;
     if (K % 32 != 0) {
         const int pr = K - 32 * (nb - 1);
-        for (int idx = tid; idx < (nb - 1) * 8; idx += 512) {
+        for (int idx = tid; idx < (nb - 1) * 8; idx += 64 * NW) {
             const int c = idx >> 3, g = (idx >> 1) & 3, hh = idx & 1;
             float4* t = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(nb - 1, c) * 1024);
             t[g * 64 + hh * 32 + pr] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -420,8 +419,10 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
 }
-void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
-    hipLaunchKernelGGL((ongpis_chol_kernel<3>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
+void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int small, hipStream_t s) {
+    // small: every cluster of the launch has at most 8 block rows -> 4 waves per workgroup, two workgroups per CU
+    if (small) hipLaunchKernelGGL((ongpis_chol_kernel<3, 4>), dim3(njobs), dim3(256), 0, s, d_models, d_jobs);
+    else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
 }  // namespace gpis
