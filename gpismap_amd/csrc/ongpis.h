@@ -90,13 +90,15 @@ private:
     int* d_jobs_ = nullptr; int cap_jobs_ = 0;   // train job table (4 ints per job)
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    hipStream_t s2_ = nullptr;                   // side stream: small factorisations run beside the large ones
+    hipEvent_t evf_ = nullptr, evj_ = nullptr;   // fork / join
 };
 
 // kernels (ongpis_train.hip / ongpis_test.hip)
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
-void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int small, hipStream_t s);
+void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;

@@ -17,6 +17,9 @@ OnGPISStore::~OnGPISStore() {
     (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_ej_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
+    if (evf_) (void)hipEventDestroy(evf_);
+    if (evj_) (void)hipEventDestroy(evj_);
+    if (s2_) (void)hipStreamDestroy(s2_);
     pool_destroy(pool_);
 }
 
@@ -152,12 +155,28 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     }
     ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
     ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
-    // Factorisation (also produces the re-tiled copy Lt).  The table is sorted by size: the tail of small
-    // clusters (K <= 256) goes to 4-wave workgroups, two per CU.
-    int nbig = 0;
-    while (nbig < nj && tab[4 * nbig + 2] + dim_ * tab[4 * nbig + 3] > 256) ++nbig;
-    if (nbig > 0) ongpis_launch_chol(d_models_, d_jobs_, nbig, 0, s);
-    if (nbig < nj) ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbig, nj - nbig, 1, s);
+    // Factorisation (also produces the re-tiled copy Lt).  The table is sorted by size; the small clusters (K <= 256)
+    // get single-wave workgroups (ongpis_launch_chol), on a side stream beside the wide ones.
+    int n0 = 0;
+    while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
+    const bool fork = n0 > 0 && n0 < nj;
+    hipStream_t sn = s;
+    if (fork) {
+        if (!s2_) {
+            GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+            GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
+            GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
+        }
+        GPIS_HIP(hipEventRecord(evf_, s));
+        GPIS_HIP(hipStreamWaitEvent(s2_, evf_, 0));
+        sn = s2_;
+    }
+    if (n0 > 0) ongpis_launch_chol(d_models_, d_jobs_, n0, 0, s);
+    if (nj > n0) ongpis_launch_chol(d_models_, d_jobs_ + 4 * n0, nj - n0, 1, sn);
+    if (fork) {
+        GPIS_HIP(hipEventRecord(evj_, s2_));
+        GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
+    }
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));

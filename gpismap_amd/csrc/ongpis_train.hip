@@ -150,7 +150,7 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 }
 
 // ---------------------------------------------------------------------------
-// K3.  grid = jobs, block = 64 NW: 8 waves, or 4 for launches of small clusters (K <= 256).
+// K3.  grid = jobs, block = 64 NW: 8 waves, or 1 for clusters with K <= 256 -- ongpis_launch_chol.
 // Left-looking 32-blocked Cholesky of rows 0..K (row K = y) with the tiles of the current block
 // column resident in MFMA accumulators:
 //   tile(bi, j) = A(bi, j) - sum_{p<j} L(bi, p) L(j, p)^T      v_mfma_f32_32x32x2_f32, ascending p and k
@@ -419,9 +419,10 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
 }
-void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int small, hipStream_t s) {
-    // small: every cluster of the launch has at most 8 block rows -> 4 waves per workgroup, two workgroups per CU
-    if (small) hipLaunchKernelGGL((ongpis_chol_kernel<3, 4>), dim3(njobs), dim3(256), 0, s, d_models, d_jobs);
+void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s) {
+    // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small
+    // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
+    if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<3, 1>), dim3(njobs), dim3(64), 0, s, d_models, d_jobs);
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
