@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=2, help="synthetic depth frames fused before testing")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
-    ap.add_argument("--cpu-sample", type=int, default=24, help="CPU baseline runs on a sample^3 subgrid (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline runs on a sample^3 subgrid (0 = skip)")
     args = ap.parse_args()
 
     import torch
