@@ -70,11 +70,9 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     // this lane's column: query slot qi, component cq
     const int qi = l31 >> 2, cq = l31 & 3;
     const bool qact = (qi < jcnt) && (cq <= dim);
-    float4 xq = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (qi < jcnt) xq = A.xq[A.job_q[joff + qi]];
 
     // optional cycle trace of one workgroup (A.trace != nullptr): [wave][slot] timestamps
-    unsigned long long* trc = (TR && A.trace && blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
+    unsigned long long* trc = (TR && A.trace && (int)blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
     int tri = 0;
 #define TRACE() do { if constexpr (TR) { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } } while (0)
     // owner-path events (traced build): [8 + wave][slot]
