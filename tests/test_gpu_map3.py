@@ -8,7 +8,8 @@ import replay
 
 pytestmark = pytest.mark.gpu
 
-NFRAMES = 6
+NFRAMES = 40                      # the whole bundled sequence (demo_gpisMap3.m)
+TEST_AT = (0, 1, 2, 5, 9, 19, 29, 39)   # test() on the demo grid after these frames; the map state is compared after every frame
 
 
 def compare_res(rg, ro, flags, tag):
@@ -53,9 +54,10 @@ def test_sequence_matches_oracle():
         # map state: positions / normals / noises, tree order.  Decisions are driven by K2 results
         # that are bit-identical to the oracle up to rare 1-ulp exp() differences.
         assert np.array_equal(ng, no), (i, float(np.abs(ng - no).max()))
-        rg = gm.test(grid); ro = om.test(grid)
-        flags = om.test_flags(grid)
-        compare_res(rg, ro, flags, "frame %d (%d pts, %d clusters)" % (i + 1, ng.shape[0], gm.stats()["clusters"]))
+        if i in TEST_AT:
+            rg = gm.test(grid); ro = om.test(grid)
+            flags = om.test_flags(grid)
+            compare_res(rg, ro, flags, "frame %d (%d pts, %d clusters)" % (i + 1, ng.shape[0], gm.stats()["clusters"]))
         if i == 0:
             st = gm.stats(); ost = om.stats()
             assert st["obsgp_groups"] == ost["obsgp_tiles"] == 154
