@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=2, help="synthetic depth frames fused before testing")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: results staged through host memory)")
     ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline runs on a sample^3 subgrid (0 = skip)")
     args = ap.parse_args()
 
@@ -50,11 +51,16 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available() or gpismap_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: gpismap_amd has no CPU fallback")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()      # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     # ---- set-up (untimed): fuse the synthetic frames; time update() per frame ----
     gm = gpismap_amd.GPisMap3()          # default camera 640x480, fx=fy=568, cx=310, cy=224
@@ -82,7 +88,13 @@ def main():
     def step():
         gm.test_device(x.data_ptr(), hi - lo, res.data_ptr(), stream)
         if world > 1:
-            sharding.gather_slabs(res, n_total, world, rank, dst=0, out=full)
+            if args.backend == "gloo":     # rehearsal path: host staging (gloo has no device P2P)
+                torch.cuda.synchronize()
+                got = sharding.gather_slabs(res.cpu(), n_total, world, rank, dst=0)
+                if rank == 0:
+                    full.copy_(got)
+            else:
+                sharding.gather_slabs(res, n_total, world, rank, dst=0, out=full)
 
     def barrier():
         if world > 1:
@@ -105,9 +117,21 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    if args.backend == "gloo" and world > 1 and rank == 0:
+        # rehearsal only: the assembled map must equal a single-rank pass over the whole grid, bit for bit
+        xf = torch.from_numpy(grid).to(dev)
+        ref = torch.zeros((n_total, 8), dtype=torch.float32, device=dev)
+        gm.test_device(xf.data_ptr(), n_total, ref.data_ptr(), stream)
+        torch.cuda.synchronize()
+        same = bool(torch.equal(ref.view(torch.int32), full.view(torch.int32)))
+        print("rehearsal (%d ranks, gloo staging): assembled map identical to a single-rank pass: %s" % (world, same), file=sys.stderr)
+        if not same:
+            raise SystemExit("multi-rank assembly differs from the single-rank result")
+        del xf, ref
 
     # ---- CPU baseline: the oracle on the host cores, bounded subsample of the same grid ----
     cpu = None
