@@ -2,21 +2,28 @@
 // the 2-D tiling, :85-143 for the 1-D groups), buffer management, H2D/D2H.
 #include <cstring>
 #include <map>
+#include <vector>
+#include <algorithm>
 #include "obsgp.h"
 
 namespace gpis {
 
 // ---------------------------------------------------------------- DevPool ----
+// Size-class free lists over large device chunks: a block is carved from the current chunk (bump pointer) the
+// first time its class is needed and recycled through its class list afterwards -- one hipMalloc per 256 MiB
+// instead of one per cluster model (the first frame allocates several hundred models).
 struct DevPool {
     std::multimap<size_t, void*> free_;
     std::map<void*, size_t> live_;
+    std::vector<void*> chunks_;
+    char* cur_ = nullptr;
+    size_t left_ = 0;
     size_t bytes = 0;
 };
 DevPool* pool_create() { return new DevPool(); }
 void pool_destroy(DevPool* p) {
     if (!p) return;
-    for (auto& kv : p->free_) (void)hipFree(kv.second);
-    for (auto& kv : p->live_) (void)hipFree(kv.first);
+    for (void* c : p->chunks_) (void)hipFree(c);
     delete p;
 }
 static size_t pool_class(size_t b) {  // 256 KiB granules above 1 MiB, 4 KiB below
@@ -29,8 +36,22 @@ void* pool_alloc(DevPool* p, size_t bytes) {
     void* ptr = nullptr;
     if (it != p->free_.end()) { ptr = it->second; p->free_.erase(it); }
     else {
-        if (hipMalloc(&ptr, c) != hipSuccess) return nullptr;
-        p->bytes += c;
+        if (c > p->left_) {
+            // the rest of the old chunk stays usable for small classes through the free lists
+            while (p->left_ >= (4u << 10)) {
+                size_t piece = p->left_ >= (256u << 10) ? (256u << 10) : (4u << 10);
+                p->free_.insert({piece, p->cur_});
+                p->cur_ += piece; p->left_ -= piece;
+            }
+            const size_t chunk = std::max<size_t>(c, (size_t)256 << 20);
+            void* base = nullptr;
+            if (hipMalloc(&base, chunk) != hipSuccess) return nullptr;
+            p->chunks_.push_back(base);
+            p->cur_ = (char*)base; p->left_ = chunk;
+            p->bytes += chunk;
+        }
+        ptr = p->cur_;
+        p->cur_ += c; p->left_ -= c;
     }
     p->live_[ptr] = c;
     return ptr;
