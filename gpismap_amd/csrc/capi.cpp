@@ -15,6 +15,8 @@ using namespace gpis;
 void gpis3_impl_stats(GPisMap3* m, double* out, int n);
 void gpis3_impl_profile(GPisMap3* m, int on);
 void gpis2_impl_stats(GPisMap* m, double* out, int n);
+int gpis3_impl_fail(GPisMap3* m);
+int gpis2_impl_fail(GPisMap* m);
 
 extern "C" {
 
@@ -53,12 +55,13 @@ int gpis3_update(void* m, const float* depth, int n, const float* pose12) {
 int gpis3_test(void* m, const float* x, int dim, int n, float* res) {
     if (!m) return GPIS_ERR_ARG;
     if (gpis_device_count() < 1) return GPIS_ERR_HIP;
-    try { return ((GPisMap3*)m)->test(const_cast<float*>(x), dim, n, res) ? GPIS_OK : GPIS_ERR_ARG; }
+    // false = the reference's own refusal (GPIS_ERR_ARG) unless the device path failed: that is reported as such
+    try { if (((GPisMap3*)m)->test(const_cast<float*>(x), dim, n, res)) return GPIS_OK; int e = gpis3_impl_fail((GPisMap3*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis3_test_device(void* m, const float* d_x, int n, float* d_res, void* stream) {
     if (!m) return GPIS_ERR_ARG;
-    try { return ((GPisMap3*)m)->testDevice(d_x, n, d_res, stream) ? GPIS_OK : GPIS_ERR_ARG; }
+    try { if (((GPisMap3*)m)->testDevice(d_x, n, d_res, stream)) return GPIS_OK; int e = gpis3_impl_fail((GPisMap3*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis3_num_points(void* m) {
@@ -98,12 +101,12 @@ int gpis2_update(void* m, const float* thetas, const float* ranges, int n, const
 int gpis2_test(void* m, const float* x, int dim, int n, float* res) {
     if (!m) return GPIS_ERR_ARG;
     if (gpis_device_count() < 1) return GPIS_ERR_HIP;
-    try { return ((GPisMap*)m)->test(const_cast<float*>(x), dim, n, res) ? GPIS_OK : GPIS_ERR_ARG; }
+    try { if (((GPisMap*)m)->test(const_cast<float*>(x), dim, n, res)) return GPIS_OK; int e = gpis2_impl_fail((GPisMap*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis2_test_device(void* m, const float* d_x, int n, float* d_res, void* stream) {
     if (!m) return GPIS_ERR_ARG;
-    try { return ((GPisMap*)m)->testDevice(d_x, n, d_res, stream) ? GPIS_OK : GPIS_ERR_ARG; }
+    try { if (((GPisMap*)m)->testDevice(d_x, n, d_res, stream)) return GPIS_OK; int e = gpis2_impl_fail((GPisMap*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis2_get_nodes(void* m, float* out, int cap) {

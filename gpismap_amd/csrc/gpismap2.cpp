@@ -48,6 +48,7 @@ FlatTreeParam tree_param2() {
 }  // namespace
 
 struct GPisMap::Impl {
+    int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T2 = FlatTree<2>;
     GPisMapParam setting;
     T2 tree;
@@ -530,24 +531,32 @@ void GPisMap::update(float* datax, float* dataf, int N, std::vector<float>& pose
 
 bool GPisMap::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) {
     Impl& m = *p_;
+    m.fail_rc = 0;
     if (!m.ok || !d_x || !d_res || leng < 1 || !m.has_tree) return false;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
-    return m.mq.run(m.store, d_x, leng, d_res, s) == GPIS_OK;
+    m.fail_rc = 0;
+    const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
+    if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap::testDevice: device path failed (%d)\n", rc); }
+    return rc == GPIS_OK;
 }
 
 bool GPisMap::test(float* x, int dim, int leng, float* res) {  // GPisMap.cpp:765-810
     Impl& m = *p_;
+    m.fail_rc = 0;
     if (x == 0 || dim != 2 || leng < 1) return false;
     if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap::test: HIP device unavailable\n"); return false; }
     if (!m.has_tree) return false;
+    m.fail_rc = 0;
+    auto fail = [&](int rc) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap::test: device path failed (%d)\n", rc); return false; };
     size_t nx = (size_t)2 * leng, nr = (size_t)6 * leng;
-    if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return false; m.cap_x = nx; }
-    if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return false; m.cap_res = nr; }
-    if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
-    if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
-    if (m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream) != GPIS_OK) return false;
-    if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return false;
-    return hipStreamSynchronize(m.stream) == hipSuccess;
+    if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_x = nx; }
+    if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_res = nr; }
+    if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    { const int rc = m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream); if (rc != GPIS_OK) return fail(rc); }
+    if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    if (hipStreamSynchronize(m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    return true;
 }
 
 void GPisMap::getAllNodes(std::vector<float>& out) {
@@ -571,3 +580,5 @@ void gpis2_impl_stats(GPisMap* g, double* out, int n) {
                     (double)m.store.last_train_ms, 0.0};
     for (int i = 0; i < n && i < 12; ++i) out[i] = v[i];
 }
+
+int gpis2_impl_fail(GPisMap* g) { return g->impl()->fail_rc; }

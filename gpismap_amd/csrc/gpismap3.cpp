@@ -64,6 +64,7 @@ FlatTreeParam tree_param3() {
 }  // namespace
 
 struct GPisMap3::Impl {
+    int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T3 = FlatTree<3>;
     GPisMap3Param setting;
     camParam cam;
@@ -637,26 +638,34 @@ void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisM
 
 bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) {
     Impl& m = *p_;
+    m.fail_rc = 0;
     if (!m.ok || !d_x || !d_res || leng < 1) return false;
     if (!m.has_tree) return false;  // the reference dereferences a null tree here
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
-    return m.mq.run(m.store, d_x, leng, d_res, s) == GPIS_OK;
+    m.fail_rc = 0;
+    const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
+    if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: device path failed (%d)\n", rc); }
+    return rc == GPIS_OK;
 }
 
 bool GPisMap3::test(float* x, int dim, int leng, float* res) {  // GPisMap3.cpp:904-949
     Impl& m = *p_;
+    m.fail_rc = 0;
     if (x == 0 || dim != 3 || leng < 1) return false;
     if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::test: HIP device unavailable\n"); return false; }
     if (!m.has_tree) return false;
+    m.fail_rc = 0;
+    auto fail = [&](int rc) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::test: device path failed (%d)\n", rc); return false; };
     size_t nx = (size_t)3 * leng, nr = (size_t)8 * leng;
-    if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return false; m.cap_x = nx; }
-    if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return false; m.cap_res = nr; }
-    if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
+    if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_x = nx; }
+    if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_res = nr; }
+    if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     // only some entries are written (callers pre-fill res, mexGPisMap3.cpp:99): start from the caller's buffer
-    if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return false;
-    if (m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream) != GPIS_OK) return false;
-    if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return false;
-    return hipStreamSynchronize(m.stream) == hipSuccess;
+    if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    { const int rc = m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream); if (rc != GPIS_OK) return fail(rc); }
+    if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    if (hipStreamSynchronize(m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
+    return true;
 }
 
 void GPisMap3::getAllPoints(std::vector<float>& pos) {  // GPisMap3.cpp:951-972
@@ -685,6 +694,7 @@ void GPisMap3::getAllNodes(std::vector<float>& out) {
 }
 
 // accessors used by the C-ABI (capi.cpp)
+int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     double v[17] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,

@@ -44,7 +44,8 @@ int   gpis3_set_camera(void* map, const gpis_cam* cam);         /* GPisMap3::res
 int   gpis3_update(void* map, const float* depth, int n, const float* pose12);
 /* x: n*3 interleaved; res: n*8 [f gx gy gz vf vgx vgy vgz], pre-filled by the caller; only the
  * entries the reference writes are touched.  Returns GPIS_ERR_ARG where the reference returns
- * false.                                                       GPisMap3::test GPisMap3.cpp:904 */
+ * false; a failure of the device path is never folded into that: GPIS_ERR_HIP / _STATE / _LIMIT.
+ *                                                             GPisMap3::test GPisMap3.cpp:904 */
 int   gpis3_test(void* map, const float* x, int dim, int n, float* res);
 int   gpis3_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
 int   gpis3_num_points(void* map);
