@@ -17,6 +17,8 @@ void gpis3_impl_profile(GPisMap3* m, int on);
 void gpis2_impl_stats(GPisMap* m, double* out, int n);
 int gpis3_impl_fail(GPisMap3* m);
 int gpis2_impl_fail(GPisMap* m);
+int gpis3_impl_update_fail(GPisMap3* m);
+int gpis2_impl_update_fail(GPisMap* m);
 
 extern "C" {
 
@@ -50,7 +52,7 @@ int gpis3_update(void* m, const float* depth, int n, const float* pose12) {
         std::vector<float> pose(pose12, pose12 + 12);
         ((GPisMap3*)m)->update(const_cast<float*>(depth), n, pose);
     } catch (...) { return GPIS_ERR_STATE; }
-    return GPIS_OK;
+    return gpis3_impl_update_fail((GPisMap3*)m);   // 0 unless a device step inside failed (bad input is silent, as in the reference)
 }
 int gpis3_test(void* m, const float* x, int dim, int n, float* res) {
     if (!m) return GPIS_ERR_ARG;
@@ -96,7 +98,7 @@ int gpis2_update(void* m, const float* thetas, const float* ranges, int n, const
         std::vector<float> pose(pose6, pose6 + 6);
         ((GPisMap*)m)->update(const_cast<float*>(thetas), const_cast<float*>(ranges), n, pose);
     } catch (...) { return GPIS_ERR_STATE; }
-    return GPIS_OK;
+    return gpis2_impl_update_fail((GPisMap*)m);
 }
 int gpis2_test(void* m, const float* x, int dim, int n, float* res) {
     if (!m) return GPIS_ERR_ARG;

@@ -48,6 +48,7 @@ FlatTreeParam tree_param2() {
 }  // namespace
 
 struct GPisMap::Impl {
+    int upd_rc = 0;    // first device-side failure inside the last update() (0: none); update() itself is void like the reference's
     int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T2 = FlatTree<2>;
     GPisMapParam setting;
@@ -103,7 +104,7 @@ struct GPisMap::Impl {
         val.assign(q.size(), 0.f); var.assign(q.size(), 1e6f);
         if (q.empty()) return true;
         int rc = gpo.query(q.data(), (int)q.size(), val.data(), var.data(), stream);
-        if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); return false; }
+        if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return false; }
         stat_obs_queries += (long)q.size();
         return true;
     }
@@ -471,7 +472,7 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
             }
             int rc = store.upload_points(soa.data(), (int)np, stream);
             if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
-            if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc);
+            if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
         }
     }
@@ -503,7 +504,7 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
         ent[i].parent = anc_index(t.par);
     }
     int rc = mq.set_clusters(ent, anc, 2.0 * (double)tree.prm.cluster_half, stream);
-    if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
 }
 
 GPisMap::GPisMap() : p_(new Impl(GPisMapParam())) {}
@@ -513,12 +514,13 @@ void GPisMap::reset() { p_->reset(); }
 
 void GPisMap::update(float* datax, float* dataf, int N, std::vector<float>& pose) {  // GPisMap.cpp:151-167
     Impl& m = *p_;
-    if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap::update: HIP device unavailable\n"); return; }
+    m.upd_rc = 0;
+    if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap::update: HIP device unavailable\n"); return; }
     m.tree.recycle();
     if (!m.preproData(datax, dataf, N, pose)) return;
     m.gpo_created = true;
     int rc = m.gpo.train1d(m.obs_theta.data(), m.obs_f.data(), m.obs_numdata, m.stream);  // regressObs :169-179 -> K1
-    if (rc != GPIS_OK || !m.gpo.trained()) { if (rc) fprintf(stderr, "[gpismap_amd] ObsGP training failed (%d)\n", rc); return; }
+    if (rc != GPIS_OK || !m.gpo.trained()) { if (rc) { fprintf(stderr, "[gpismap_amd] ObsGP training failed (%d)\n", rc); if (!m.upd_rc) m.upd_rc = rc; } return; }
     m.updateMapPoints();
     if (!m.has_tree) {
         float c[2] = {0.f, 0.f};
@@ -582,3 +584,4 @@ void gpis2_impl_stats(GPisMap* g, double* out, int n) {
 }
 
 int gpis2_impl_fail(GPisMap* g) { return g->impl()->fail_rc; }
+int gpis2_impl_update_fail(GPisMap* g) { return g->impl()->upd_rc; }

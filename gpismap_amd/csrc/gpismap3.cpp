@@ -64,6 +64,7 @@ FlatTreeParam tree_param3() {
 }  // namespace
 
 struct GPisMap3::Impl {
+    int upd_rc = 0;    // first device-side failure inside the last update() (0: none); update() itself is void like the reference's
     int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T3 = FlatTree<3>;
     GPisMap3Param setting;
@@ -190,7 +191,7 @@ bool GPisMap3::Impl::regressObs() {  // :239-256 -> K1
     if (2 * obs_zinv.size() != vu_grid.size()) return false;
     int ni = cam.height / setting.obs_skip, nj = cam.width / setting.obs_skip;
     int rc = gpo.train2d(vu_grid.data(), obs_zinv.data(), ni, nj, stream);
-    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP training failed (%d)\n", rc); return false; }
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return false; }
     return gpo.trained();
 }
 
@@ -231,7 +232,7 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
         q[2 * i + 1] = front[i] ? x_loc / z_loc : 1e30f;
     }
     int rc = gpo.query(q.data(), n, val.data(), var.data(), stream);
-    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); return; }
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += n;
     const float delx = setting.delx;
     std::vector<float> q2((size_t)12 * n, 1e30f);
@@ -277,7 +278,7 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
         }
     }
     rc = gpo.query(q2.data(), 6 * n, pval.data(), pvar.data(), stream);
-    if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
     stat_obs_queries += 6 * (long)n;
 }
 
@@ -461,7 +462,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         }
     }
     int rc = gpo.query(q.data(), 7 * n, val.data(), var.data(), stream);
-    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); return; }
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += 7 * (long)n;
 
     for (int k = 0; k < n; ++k) {
@@ -553,7 +554,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
             }
             int rc = store.upload_points(soa.data(), (int)np, stream);
             if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
-            if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc);
+            if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
         }
     }
@@ -591,7 +592,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         if (mm && mm->base) stat_model_bytes += 4.0 * (3.0 * mm->N + mm->K + 0.5 * (double)mm->K * (mm->K + 1));
     }
     int rc = mq.set_clusters(ent, anc, 2.0 * (double)kCleng, stream);
-    if (rc != GPIS_OK) fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
 }
 
 // --------------------------------------------------------------- public surface ----
@@ -609,7 +610,8 @@ void GPisMap3::resetCam(camParam c) {  // GPisMap3.cpp:117-123
 
 void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisMap3.cpp:218-237
     Impl& m = *p_;
-    if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
+    m.upd_rc = 0;
+    if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
     m.tree.recycle();
     auto t0 = std::chrono::steady_clock::now();
     auto lap = [&](int i) {
@@ -695,6 +697,7 @@ void GPisMap3::getAllNodes(std::vector<float>& out) {
 
 // accessors used by the C-ABI (capi.cpp)
 int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
+int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     double v[17] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
