@@ -105,6 +105,31 @@ def test_train_and_predict_match_oracle(dim, scale, sizes):
     assert d_vg < 1e-4         # relative to the prior 3/s^2
 
 
+@pytest.mark.parametrize("n", [32, 33, 64, 65, 128, 129, 256, 257, 512, 513])
+def test_size_class_boundaries(n):
+    """Clusters whose K = 4 N sits exactly on / just past a size-class boundary of K3 and K4 (K = 128, 256, 512,
+    1024, 2048 are multiples of 32: no padding rows inside the last block, the y row lives in a block of its
+    own) -- factor, alpha and predictions bit-identical to the oracle, including partial query tiles."""
+    import gpismap_amd
+    dim, scale = 3, 0.04
+    rng = np.random.default_rng(1000 + n)
+    pos, grad, val, sx, sg = make_cluster(rng, dim, n, scale, frac_nograd=0.0)
+    st = gpismap_amd.OnGPIS(dim, scale)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    o = oracle_lib.ongpis_train(dim, scale, pos, grad, val, sx, sg)
+    g = st.model(models[0])
+    K = o["K"]
+    assert g["K"] == K == 4 * n
+    assert np.array_equal(np.tril(g["L"][:K, :K]), np.tril(o["L"]))
+    assert np.array_equal(g["alpha"][:K], o["alpha"])
+    nq = 21                                       # 2 full tiles + a partial one
+    xq = (pos[rng.integers(0, n, nq)] + rng.normal(0, 0.3 * scale, (nq, dim))).astype(np.float32)
+    ref = oracle_lib.ongpis_predict(dim, scale, pos, grad, val, sx, sg, xq)
+    out = st.eval(xq, np.arange(nq, dtype=np.int32), np.full(nq, models[0], dtype=np.int32))
+    got = np.concatenate([out[:, :4], out[:, 4:8]], axis=1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_predict_without_exp_table_is_identical(monkeypatch):
     """Clusters too large for the per-tile exp table in LDS take a path that evaluates exp() per kernel
     entry (GPIS_K4_NOTABLE forces it): results must not change by a bit."""
