@@ -105,10 +105,10 @@ def test_train_and_predict_match_oracle(dim, scale, sizes):
     assert d_vg < 1e-4         # relative to the prior 3/s^2
 
 
-@pytest.mark.parametrize("n", [32, 33, 64, 65, 128, 129, 256, 257, 512, 513])
+@pytest.mark.parametrize("n", [32, 33, 64, 65, 128, 129, 256, 257, 512, 513, 768])
 def test_size_class_boundaries(n):
     """Clusters whose K = 4 N sits exactly on / just past a size-class boundary of K3 and K4 (K = 128, 256, 512,
-    1024, 2048 are multiples of 32: no padding rows inside the last block, the y row lives in a block of its
+    1024, 2048 and the maximum 3072 are multiples of 32: no padding rows in the last block, the y row lives in a block of its
     own) -- factor, alpha and predictions bit-identical to the oracle, including partial query tiles."""
     import gpismap_amd
     dim, scale = 3, 0.04
