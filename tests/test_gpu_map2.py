@@ -23,7 +23,7 @@ def test_2d_sequence_matches_oracle():
         ng, no = gm.nodes(), om.nodes()
         assert ng.shape == no.shape, (i, ng.shape, no.shape)
         assert np.array_equal(ng, no), (i, float(np.abs(ng - no).max()))
-        if i in (0, 9, 27):
+        if True:      # test() on the demo grid after every frame (the 2-D oracle is fast)
             rg, ro = gm.test(grid), om.test(grid)
             fl = om.test_flags(grid)
             ok = np.ones(grid.shape[0], dtype=bool)       # nothing masked

@@ -85,3 +85,20 @@ def test_untouched_entries_and_prior():
     gm.reset()
     assert gm.test(far) is None
     assert gm.num_points() == 0
+
+
+@pytest.mark.parametrize("noise", [False, True])
+def test_synthetic_frames_match_oracle(noise):
+    """BASELINE config 4 inputs (640x480 synthetic depth, optionally with the 1 mm noise variant of SURVEY 8d):
+    map state after each of two frames and test() on a 40^3 sample of the query volume, against the oracle."""
+    import gpismap_amd
+    gm = gpismap_amd.GPisMap3()
+    om = oracle_lib.OracleMap3()
+    g = replay.synthetic_grid(40)
+    for f in range(2):
+        d = replay.synthetic_depth(f, noise=noise)
+        gm.update(d, replay.IDENTITY_POSE); om.update(d, replay.IDENTITY_POSE)
+        ng, no = gm.nodes(), om.nodes()
+        assert ng.shape == no.shape and np.array_equal(ng, no)
+        rg, ro = gm.test(g), om.test(g)
+        compare_res(rg, ro, om.test_flags(g), "synthetic%s frame %d (%d pts, %d clusters)" % (" + noise" if noise else "", f + 1, ng.shape[0], gm.stats()["clusters"]))
