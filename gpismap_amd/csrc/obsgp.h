@@ -48,7 +48,9 @@ public:
     int trained_groups(hipStream_t s);
     // debug / parity: copy one group back (n, x[128], alpha[64], L[4096])
     int get_group(int g, int* n, float* x, float* alpha, float* L, hipStream_t s);
-    void reset_trained() { trained_ = false; }
+    // map reset(): the reference deletes its ObsGP object (GPisMap3.cpp:105-108), so the partition kept across
+    // frames goes with it and the next train2d() partitions afresh
+    void reset_trained() { trained_ = false; sz0_ = sz1_ = 0; }
 
 private:
     int ensure_groups(int ngroups);

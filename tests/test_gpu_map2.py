@@ -47,3 +47,23 @@ def test_2d_sequence_matches_oracle():
     rg = gm.test(grid)
     assert abs(int((rg[:, 3] < 0.4).sum()) - 18720) <= 3
     assert abs(float(rg[:, 0].mean()) - (-0.0838)) < 1e-4
+
+
+def test_2d_reset_gives_a_fresh_map():
+    """reset() (GPisMap.cpp:90) leaves nothing behind: replaying frames after it equals a fresh map bit for bit."""
+    import gpismap_amd
+    frames = replay.load_gazebo()
+    grid = replay.demo2_grid()[::7]
+    a = gpismap_amd.GPisMap()
+    for fr in frames[:4]:
+        a.update(fr["thetas"], fr["ranges"], fr["pose"])
+    ra, na = a.test(grid), a.nodes()
+    b = gpismap_amd.GPisMap()
+    for fr in frames[10:13]:
+        b.update(fr["thetas"], fr["ranges"], fr["pose"])
+    b.reset()
+    assert b.test(grid) is None
+    for fr in frames[:4]:
+        b.update(fr["thetas"], fr["ranges"], fr["pose"])
+    assert np.array_equal(b.nodes(), na)
+    assert np.array_equal(b.test(grid).view(np.uint32), ra.view(np.uint32))

@@ -102,3 +102,29 @@ def test_synthetic_frames_match_oracle(noise):
         assert ng.shape == no.shape and np.array_equal(ng, no)
         rg, ro = gm.test(g), om.test(g)
         compare_res(rg, ro, om.test_flags(g), "synthetic%s frame %d (%d pts, %d clusters)" % (" + noise" if noise else "", f + 1, ng.shape[0], gm.stats()["clusters"]))
+
+
+def test_reset_gives_a_fresh_map():
+    """reset() (GPisMap3.cpp:99) must leave nothing behind: replaying frames after it reproduces a fresh map's
+    state and predictions bit for bit (model slots, point ids and device pools are recycled underneath)."""
+    import gpismap_amd
+    frames = replay.load_bigbird()
+    grid = replay.demo3_grid()
+    a = gpismap_amd.GPisMap3(frames[0]["cam"])
+    for i in (0, 1, 2):
+        if i:
+            a.set_camera(frames[i]["cam"])
+        a.update(frames[i]["depth"], frames[i]["pose"])
+    ra, na = a.test(grid), a.nodes()
+    # a map that saw other data first, then reset
+    b = gpismap_amd.GPisMap3(frames[5]["cam"])
+    for i in (5, 6):
+        b.set_camera(frames[i]["cam"])
+        b.update(frames[i]["depth"], frames[i]["pose"])
+    b.reset()
+    assert b.num_points() == 0 and b.test(grid) is None
+    for i in (0, 1, 2):
+        b.set_camera(frames[i]["cam"])
+        b.update(frames[i]["depth"], frames[i]["pose"])
+    assert np.array_equal(b.nodes(), na)
+    assert np.array_equal(b.test(grid).view(np.uint32), ra.view(np.uint32))
