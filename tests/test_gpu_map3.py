@@ -128,3 +128,34 @@ def test_reset_gives_a_fresh_map():
         b.update(frames[i]["depth"], frames[i]["pose"])
     assert np.array_equal(b.nodes(), na)
     assert np.array_equal(b.test(grid).view(np.uint32), ra.view(np.uint32))
+
+
+def test_two_maps_in_one_process_and_caller_stream():
+    """Two map objects driven alternately (no hidden process-global state), and test_device() on a caller's
+    stream with queries/results resident in HBM: both must reproduce the single-map, host-buffer results."""
+    import torch
+    import gpismap_amd
+    frames = replay.load_bigbird()
+    grid = replay.demo3_grid()
+    solo = gpismap_amd.GPisMap3(frames[0]["cam"])
+    solo.update(frames[0]["depth"], frames[0]["pose"])
+    r0 = solo.test(grid)
+    solo.set_camera(frames[1]["cam"]); solo.update(frames[1]["depth"], frames[1]["pose"])
+    r1 = solo.test(grid)
+    a = gpismap_amd.GPisMap3(frames[0]["cam"])
+    b = gpismap_amd.GPisMap3(frames[0]["cam"])
+    a.update(frames[0]["depth"], frames[0]["pose"])
+    b.update(frames[0]["depth"], frames[0]["pose"])
+    a.set_camera(frames[1]["cam"]); a.update(frames[1]["depth"], frames[1]["pose"])
+    assert np.array_equal(b.test(grid).view(np.uint32), r0.view(np.uint32))      # b unaffected by a's second frame
+    assert np.array_equal(a.test(grid).view(np.uint32), r1.view(np.uint32))
+    # device-resident queries on a side stream
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    x = torch.from_numpy(grid).to(dev)
+    res = torch.zeros((grid.shape[0], 8), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        a.test_device(x.data_ptr(), grid.shape[0], res.data_ptr(), st.cuda_stream)
+    st.synchronize()
+    assert np.array_equal(res.cpu().numpy().view(np.uint32), r1.view(np.uint32))
