@@ -23,4 +23,13 @@ def _native_built():
     if not os.path.exists(gpismap_amd.LIB_PATH):
         import __graft_entry__
         __graft_entry__.build()
+    # torch ships its own copy of the HIP runtime; a test that hands device tensors to the library needs torch's
+    # runtime up as well.  Bring it up first (as bench.py does): initialising it late, after many library-side
+    # streams exist in the process, was seen to fail with "No HIP GPUs are available".
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
     yield
