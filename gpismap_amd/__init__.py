@@ -42,6 +42,9 @@ def lib():
     vp = C.c_void_p
     L.gpis_device_count.restype = C.c_int
     L.gpis_version.restype = C.c_char_p
+    L.gpis_set_device.argtypes = [C.c_int]
+    L.gpis3_device.argtypes = [vp]
+    L.gpis2_device.argtypes = [vp]
     L.gpis3_create.restype = vp
     L.gpis3_create.argtypes = [C.POINTER(gpis_cam)]
     L.gpis3_destroy.argtypes = [vp]
@@ -78,12 +81,22 @@ def lib():
     L.gpis_ongpis_get_model.argtypes = [vp, C.c_int, fp, fp, ip]
     L.gpis_ongpis_eval.argtypes = [vp, fp, C.c_int, ip, ip, C.c_int, fp]
     L.gpis_ongpis_last_ms.argtypes = [vp, fp, fp]
+    L.gpis_ongpis_set_exp_table.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
 
 def device_count():
     return lib().gpis_device_count()
+
+
+def set_device(device):
+    """Select the HIP device for every object created afterwards (one process per GPU: LOCAL_RANK)."""
+    _check(lib().gpis_set_device(int(device)), "gpis_set_device(%d)" % int(device))
+
+
+def get_device():
+    return lib().gpis_get_device()
 
 
 def _check(rc, what):
@@ -147,6 +160,9 @@ class GPisMap3:
     def test_device(self, d_x_ptr, n, d_res_ptr, stream=0):
         _check(self.L.gpis3_test_device(self.h, C.c_void_p(d_x_ptr), n, C.c_void_p(d_res_ptr), C.c_void_p(stream)),
                "gpis3_test_device")
+
+    def device(self):
+        return self.L.gpis3_device(self.h)
 
     def num_points(self):
         return self.L.gpis3_num_points(self.h)
@@ -318,6 +334,9 @@ class OnGPIS:
         _check(self.L.gpis_ongpis_eval(self.h, _p(xq), xq.shape[0], _p(job_q, C.c_int), _p(job_model, C.c_int), job_q.size,
                                        _p(out)), "gpis_ongpis_eval")
         return out
+
+    def set_exp_table(self, on=True):
+        _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")
 
     def last_ms(self):
         a, b = C.c_float(0), C.c_float(0)

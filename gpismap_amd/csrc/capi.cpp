@@ -19,6 +19,8 @@ int gpis3_impl_fail(GPisMap3* m);
 int gpis2_impl_fail(GPisMap* m);
 int gpis3_impl_update_fail(GPisMap3* m);
 int gpis2_impl_update_fail(GPisMap* m);
+int gpis3_impl_device(GPisMap3* m);
+int gpis2_impl_device(GPisMap* m);
 
 extern "C" {
 
@@ -27,7 +29,17 @@ int gpis_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
-const char* gpis_version(void) { return "gpismap_amd 0.1 (gfx950)"; }
+const char* gpis_version(void) { return "gpismap_amd 0.2 (gfx950)"; }
+int gpis_set_device(int device) {
+    int n = gpis_device_count();
+    if (device < 0 || device >= n) return GPIS_ERR_ARG;
+    return hipSetDevice(device) == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
+}
+int gpis_get_device(void) {
+    int d = -1;
+    if (hipGetDevice(&d) != hipSuccess) return GPIS_ERR_HIP;
+    return d;
+}
 
 // ---- 3-D map ----------------------------------------------------------------
 void* gpis3_create(const gpis_cam* cam) {
@@ -66,6 +78,7 @@ int gpis3_test_device(void* m, const float* d_x, int n, float* d_res, void* stre
     try { if (((GPisMap3*)m)->testDevice(d_x, n, d_res, stream)) return GPIS_OK; int e = gpis3_impl_fail((GPisMap3*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
+int gpis3_device(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_device((GPisMap3*)m); }
 int gpis3_num_points(void* m) {
     if (!m) return GPIS_ERR_ARG;
     std::vector<float> p; ((GPisMap3*)m)->getAllPoints(p); return (int)(p.size() / 3);
@@ -111,6 +124,7 @@ int gpis2_test_device(void* m, const float* d_x, int n, float* d_res, void* stre
     try { if (((GPisMap*)m)->testDevice(d_x, n, d_res, stream)) return GPIS_OK; int e = gpis2_impl_fail((GPisMap*)m); return e ? e : GPIS_ERR_ARG; }
     catch (...) { return GPIS_ERR_STATE; }
 }
+int gpis2_device(void* m) { if (!m) return GPIS_ERR_ARG; return gpis2_impl_device((GPisMap*)m); }
 int gpis2_get_nodes(void* m, float* out, int cap) {
     if (!m) return GPIS_ERR_ARG;
     std::vector<float> p; ((GPisMap*)m)->getAllNodes(p);
@@ -218,6 +232,11 @@ int gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const i
     if (rc) return rc;
     GPIS_HIP(hipMemcpyAsync(out8, h->d_out, sizeof(float) * no, hipMemcpyDeviceToHost, h->s));
     GPIS_HIP(hipStreamSynchronize(h->s));
+    return GPIS_OK;
+}
+int gpis_ongpis_set_exp_table(void* s, int on) {
+    if (!s) return GPIS_ERR_ARG;
+    ((OnHandle*)s)->st.use_exp_table = on != 0;
     return GPIS_OK;
 }
 int gpis_ongpis_last_ms(void* s, float* t, float* e) {

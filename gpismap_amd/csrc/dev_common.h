@@ -57,6 +57,20 @@ __device__ __forceinline__ float d_dist3(float ax, float ay, float az, float bx,
     return sqrtf((tx * tx + ty * ty) + tz * tz);
 }
 
+// Every map object lives on ONE device: the device current in the creating thread (gpis_set_device, or the
+// caller's own hipSetDevice) at construction.  Each public entry point makes that device current for its
+// duration and restores the caller's afterwards, so one process can drive maps on several GPUs and a rank of
+// a multi-GPU job never lands on device 0 by accident.
+struct DeviceScope {
+    int prev = -1, dev = -1;
+    explicit DeviceScope(int d) : dev(d) {
+        if (d < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) { prev = -1; return; }
+        if (prev != d) (void)hipSetDevice(d);
+    }
+    ~DeviceScope() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
+};
+
 // Simple caching device allocator (size-class free lists).  Not thread safe:
 // one map object = one caller thread, as in the reference.
 struct DevPool;

@@ -48,6 +48,7 @@ FlatTreeParam tree_param2() {
 }  // namespace
 
 struct GPisMap::Impl {
+    int device = -1;   // HIP device this map lives on (current device at construction)
     int upd_rc = 0;    // first device-side failure inside the last update() (0: none); update() itself is void like the reference's
     int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T2 = FlatTree<2>;
@@ -69,7 +70,8 @@ struct GPisMap::Impl {
     explicit Impl(const GPisMapParam& par)
         : setting(par), tree(tree_param2()), store(2, par.map_scale_param),
           mq(2, (float)((double)par.map_scale_param * 4.0), 0.4f, (float)(1.0 + (double)par.map_noise_param)) {
-        ok = (hipStreamCreate(&stream) == hipSuccess);
+        ok = (hipGetDevice(&device) == hipSuccess) && (hipStreamCreate(&stream) == hipSuccess);
+        if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap: no usable HIP device; update()/test() will fail\n");
     }
     ~Impl() {
@@ -500,19 +502,32 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
         const T2::TNode& t = tree.nodes[cl[i]];
         for (int d = 0; d < 2; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
         ent[i].c[2] = 0.f; ent[i].lo[2] = 0.f; ent[i].hi[2] = 0.f;
-        ent[i].model = t.model;
+        { const ClusterModel* mm = store.model(t.model); ent[i].model = (mm && mm->base) ? t.model : -1; }
         ent[i].parent = anc_index(t.par);
     }
     int rc = mq.set_clusters(ent, anc, 2.0 * (double)tree.prm.cluster_half, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
 }
 
+// The reference's gateways call the class methods directly (mexGPisMap3.cpp:70,102,150; mexGPisMap.cpp:70,108):
+// nothing may propagate out of them into MATLAB.  Every public method is a function-try-block.
+static void nothrow_report(const char* where, const char* what) {
+    fprintf(stderr, "[gpismap_amd] %s: exception contained (%s)\n", where, what);
+}
+
 GPisMap::GPisMap() : p_(new Impl(GPisMapParam())) {}
 GPisMap::GPisMap(GPisMapParam par) : p_(new Impl(par)) {}
-GPisMap::~GPisMap() { delete p_; }
-void GPisMap::reset() { p_->reset(); }
+GPisMap::~GPisMap() {
+    DeviceScope dev_scope_(p_->device);
+    delete p_;
+}
+void GPisMap::reset() try {
+    DeviceScope dev_scope_(p_->device);
+    p_->reset();
+} catch (const std::exception& e) { nothrow_report("GPisMap::reset", e.what()); } catch (...) { nothrow_report("GPisMap::reset", "unknown exception"); }
 
-void GPisMap::update(float* datax, float* dataf, int N, std::vector<float>& pose) {  // GPisMap.cpp:151-167
+void GPisMap::update(float* datax, float* dataf, int N, std::vector<float>& pose) try {  // GPisMap.cpp:151-167
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.upd_rc = 0;
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap::update: HIP device unavailable\n"); return; }
@@ -529,9 +544,10 @@ void GPisMap::update(float* datax, float* dataf, int N, std::vector<float>& pose
     }
     m.evalPoints();
     m.updateGPs();
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap::update", e.what()); p_->upd_rc = GPIS_ERR_STATE; } catch (...) { nothrow_report("GPisMap::update", "unknown exception"); p_->upd_rc = GPIS_ERR_STATE; }
 
-bool GPisMap::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) {
+bool GPisMap::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) try {
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.fail_rc = 0;
     if (!m.ok || !d_x || !d_res || leng < 1 || !m.has_tree) return false;
@@ -540,9 +556,10 @@ bool GPisMap::testDevice(const float* d_x, int leng, float* d_res, void* hip_str
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
     if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap::testDevice: device path failed (%d)\n", rc); }
     return rc == GPIS_OK;
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap::testDevice", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap::testDevice", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
-bool GPisMap::test(float* x, int dim, int leng, float* res) {  // GPisMap.cpp:765-810
+bool GPisMap::test(float* x, int dim, int leng, float* res) try {  // GPisMap.cpp:765-810
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.fail_rc = 0;
     if (x == 0 || dim != 2 || leng < 1) return false;
@@ -559,9 +576,9 @@ bool GPisMap::test(float* x, int dim, int leng, float* res) {  // GPisMap.cpp:76
     if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     if (hipStreamSynchronize(m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     return true;
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap::test", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap::test", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
-void GPisMap::getAllNodes(std::vector<float>& out) {
+void GPisMap::getAllNodes(std::vector<float>& out) try {
     out.clear();
     Impl& m = *p_;
     if (!m.has_tree) return;
@@ -572,7 +589,7 @@ void GPisMap::getAllNodes(std::vector<float>& out) {
         out.push_back(p.pos[0]); out.push_back(p.pos[1]); out.push_back(p.grad[0]); out.push_back(p.grad[1]);
         out.push_back(p.val); out.push_back(p.sigx); out.push_back(p.sigg);
     }
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap::getAllNodes", e.what()); } catch (...) { nothrow_report("GPisMap::getAllNodes", "unknown exception"); }
 
 void gpis2_impl_stats(GPisMap* g, double* out, int n) {
     GPisMap::Impl& m = *g->impl();
@@ -584,4 +601,5 @@ void gpis2_impl_stats(GPisMap* g, double* out, int n) {
 }
 
 int gpis2_impl_fail(GPisMap* g) { return g->impl()->fail_rc; }
+int gpis2_impl_device(GPisMap* g) { return g->impl()->device; }
 int gpis2_impl_update_fail(GPisMap* g) { return g->impl()->upd_rc; }

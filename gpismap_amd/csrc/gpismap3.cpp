@@ -64,6 +64,7 @@ FlatTreeParam tree_param3() {
 }  // namespace
 
 struct GPisMap3::Impl {
+    int device = -1;   // HIP device this map lives on (current device at construction)
     int upd_rc = 0;    // first device-side failure inside the last update() (0: none); update() itself is void like the reference's
     int fail_rc = 0;   // last device-side failure of test()/testDevice() (0: none) -- the C-ABI reports it instead of "false"
     using T3 = FlatTree<3>;
@@ -96,7 +97,8 @@ struct GPisMap3::Impl {
     Impl(const GPisMap3Param& par, const camParam& c)
         : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
           mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
-        ok = (hipStreamCreate(&stream) == hipSuccess);
+        ok = (hipGetDevice(&device) == hipSuccess) && (hipStreamCreate(&stream) == hipSuccess);
+        if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
     ~Impl() {
@@ -583,7 +585,8 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     for (size_t i = 0; i < cl.size(); ++i) {
         const T3::TNode& t = tree.nodes[cl[i]];
         for (int d = 0; d < 3; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
-        ent[i].model = t.model;
+        // a cell whose training failed (allocation) has a live slot without a factor: no GP for test() (prior only)
+        { const ClusterModel* mm = store.model(t.model); ent[i].model = (mm && mm->base) ? t.model : -1; }
         ent[i].parent = anc_index(t.par);
     }
     stat_model_bytes = 0;
@@ -596,19 +599,33 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
 }
 
 // --------------------------------------------------------------- public surface ----
+// The reference's gateways call the class methods directly (mexGPisMap3.cpp:70,102,150; mexGPisMap.cpp:70,108):
+// nothing may propagate out of them into MATLAB.  Every public method is a function-try-block.
+static void nothrow_report(const char* where, const char* what) {
+    fprintf(stderr, "[gpismap_amd] %s: exception contained (%s)\n", where, what);
+}
+
 GPisMap3::GPisMap3() : p_(new Impl(GPisMap3Param(), camParam())) {}
 GPisMap3::GPisMap3(GPisMap3Param par) : p_(new Impl(par, camParam())) {}
 GPisMap3::GPisMap3(GPisMap3Param par, camParam c) : p_(new Impl(par, c)) {}
-GPisMap3::~GPisMap3() { delete p_; }
-
-void GPisMap3::reset() { p_->reset(); }
-
-void GPisMap3::resetCam(camParam c) {  // GPisMap3.cpp:117-123
-    p_->cam = c;
-    p_->vu_grid.clear();
+GPisMap3::~GPisMap3() {
+    DeviceScope dev_scope_(p_->device);
+    delete p_;
 }
 
-void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisMap3.cpp:218-237
+void GPisMap3::reset() try {
+    DeviceScope dev_scope_(p_->device);
+    p_->reset();
+} catch (const std::exception& e) { nothrow_report("GPisMap3::reset", e.what()); } catch (...) { nothrow_report("GPisMap3::reset", "unknown exception"); }
+
+void GPisMap3::resetCam(camParam c) try {  // GPisMap3.cpp:117-123
+    DeviceScope dev_scope_(p_->device);
+    p_->cam = c;
+    p_->vu_grid.clear();
+} catch (const std::exception& e) { nothrow_report("GPisMap3::resetCam", e.what()); } catch (...) { nothrow_report("GPisMap3::resetCam", "unknown exception"); }
+
+void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) try {  // GPisMap3.cpp:218-237
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.upd_rc = 0;
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
@@ -636,9 +653,10 @@ void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) {  // GPisM
         m.updateGPs();
         lap(4);
     }
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap3::update", e.what()); p_->upd_rc = GPIS_ERR_STATE; } catch (...) { nothrow_report("GPisMap3::update", "unknown exception"); p_->upd_rc = GPIS_ERR_STATE; }
 
-bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) {
+bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) try {
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.fail_rc = 0;
     if (!m.ok || !d_x || !d_res || leng < 1) return false;
@@ -648,9 +666,10 @@ bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_st
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
     if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: device path failed (%d)\n", rc); }
     return rc == GPIS_OK;
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap3::testDevice", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::testDevice", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
-bool GPisMap3::test(float* x, int dim, int leng, float* res) {  // GPisMap3.cpp:904-949
+bool GPisMap3::test(float* x, int dim, int leng, float* res) try {  // GPisMap3.cpp:904-949
+    DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.fail_rc = 0;
     if (x == 0 || dim != 3 || leng < 1) return false;
@@ -668,9 +687,9 @@ bool GPisMap3::test(float* x, int dim, int leng, float* res) {  // GPisMap3.cpp:
     if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     if (hipStreamSynchronize(m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     return true;
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap3::test", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::test", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
-void GPisMap3::getAllPoints(std::vector<float>& pos) {  // GPisMap3.cpp:951-972
+void GPisMap3::getAllPoints(std::vector<float>& pos) try {  // GPisMap3.cpp:951-972
     pos.clear();
     Impl& m = *p_;
     if (!m.has_tree) return;
@@ -678,9 +697,9 @@ void GPisMap3::getAllPoints(std::vector<float>& pos) {  // GPisMap3.cpp:951-972
     m.tree.all_points(m.tree.root, ids);
     pos.reserve(ids.size() * 3);
     for (int id : ids) for (int d = 0; d < 3; ++d) pos.push_back(m.tree.pts[id].pos[d]);
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap3::getAllPoints", e.what()); } catch (...) { nothrow_report("GPisMap3::getAllPoints", "unknown exception"); }
 
-void GPisMap3::getAllNodes(std::vector<float>& out) {
+void GPisMap3::getAllNodes(std::vector<float>& out) try {
     out.clear();
     Impl& m = *p_;
     if (!m.has_tree) return;
@@ -693,10 +712,11 @@ void GPisMap3::getAllNodes(std::vector<float>& out) {
         for (int d = 0; d < 3; ++d) out.push_back(p.grad[d]);
         out.push_back(p.val); out.push_back(p.sigx); out.push_back(p.sigg);
     }
-}
+} catch (const std::exception& e) { nothrow_report("GPisMap3::getAllNodes", e.what()); } catch (...) { nothrow_report("GPisMap3::getAllNodes", "unknown exception"); }
 
 // accessors used by the C-ABI (capi.cpp)
 int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
+int gpis3_impl_device(GPisMap3* g) { return g->impl()->device; }
 int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();

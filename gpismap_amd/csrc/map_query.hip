@@ -316,7 +316,11 @@ __global__ __launch_bounds__(256) void blend_kernel(const int* __restrict__ cand
     for (int c = 0; c < NC; ++c) { f2[0][c] = r[c]; v2[0][c] = r[NC + c]; }
     for (int s = 1; s < nc; ++s) {
         const float* o = out + ((size_t)cap + 2 * (size_t)q + (s - 1)) * 8;
-        for (int c = 0; c < NC; ++c) { f2[s][c] = o[c]; v2[s][c] = o[4 + c]; }
+        // A cell without a trained model (point stored through the set-less root-growth insert, or a failed
+        // training) got no pass-2 job: its record is stale scratch.  The reference dereferences a null GP there;
+        // here the candidate contributes the prior (mean 0, prior variance) instead of garbage.
+        const bool has = cand[(size_t)s * cap + q] >= 0;
+        for (int c = 0; c < NC; ++c) { f2[s][c] = has ? o[c] : 0.f; v2[s][c] = has ? o[4 + c] : (c == 0 ? prior_var : 0.f); }
     }
     // stable insertion sort of <= 3 indices by value variance (std::sort on <= 16 elements)
     int id[3] = {0, 1, 2};
@@ -426,6 +430,7 @@ int MapQuery::ensure_scratch(int n, int nmodels) {
         (void)hipFree(d_xq_); (void)hipFree(d_cand_); (void)hipFree(d_ncand_); (void)hipFree(d_jm_); (void)hipFree(d_jq_);
         (void)hipFree(d_jo_); (void)hipFree(d_out_); (void)hipFree(d_tile_);
         d_xq_ = nullptr; d_cand_ = d_ncand_ = d_jm_ = d_jq_ = d_jo_ = d_tile_ = nullptr; d_out_ = nullptr; cap_n_ = 0;
+        tile_cap_ = 0;   // d_tile_ is gone: the size check below must reallocate it even when need_tiles did not grow
         size_t c = (size_t)n;
         GPIS_HIP(hipMalloc(&d_xq_, sizeof(float4) * c));
         GPIS_HIP(hipMalloc(&d_cand_, sizeof(int) * 3 * c));

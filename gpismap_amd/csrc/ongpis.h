@@ -73,9 +73,11 @@ public:
     float last_train_ms = 0.f, last_eval_ms = 0.f;
     long long last_eval_flops = 0;
     bool profile = false;
+    bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
 
 private:
     int alloc_model(int slot, int N, int ng);
+    int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc);
     int dim_;
     float scale_;
     DevPool* pool_;
@@ -118,6 +120,7 @@ struct EvalArgs {
 // K4 size classes by nb = ceil(K/32): 0: nb<=4 (1 wave x 4 tiles), 1: <=8 (2x4), 2: <=16 (4x4),
 // 3: <=32 (8x4), 4: <=64 (16x4), 5: <=96 (8x12); -1 -> cluster too large for this build (K > 3072)
 #define ONGPIS_NCLASS 6
+#define ONGPIS_MAX_K 3072
 __host__ __device__ inline int ongpis_class_of_nb(int nb) {
     return nb <= 4 ? 0 : (nb <= 8 ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : (nb <= 64 ? 4 : 5))));
 }

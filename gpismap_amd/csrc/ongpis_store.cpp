@@ -112,18 +112,46 @@ int OnGPISStore::upload_points(const float* soa9, int n, hipStream_t s) {
 int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s) {
     int nj = (int)jobs.size();
     if (nj == 0) return GPIS_OK;
-    std::vector<int> tab((size_t)4 * nj);
+    // Pass 1: validate every job before any model is touched (a refusal half-way through must not leave earlier
+    // jobs pointing at recycled, untrained memory).
     for (int j = 0; j < nj; ++j) {
         const TrainJob& tj = jobs[j];
-        if (tj.model < 0 || tj.model >= (int)models_.size() || !live_[tj.model] || tj.n <= 0) return GPIS_ERR_ARG;
+        if (tj.model < 0 || tj.model >= (int)models_.size() || !live_[tj.model] || tj.n <= 0 || tj.ng < 0 || tj.ng > tj.n ||
+            tj.off < 0 || (size_t)tj.off + (size_t)tj.n > ids.size())
+            return GPIS_ERR_ARG;
+    }
+    // Pass 2: allocate.  A cluster this build cannot hold keeps its previous model (the rest of the batch is still
+    // trained and the error reported); an allocation failure leaves that model UNTRAINED (base = nullptr: test()
+    // treats the cell as having no GP) instead of half-initialised.
+    int deferred_rc = GPIS_OK;
+    std::vector<TrainJob> ok_jobs;
+    ok_jobs.reserve(nj);
+    for (int j = 0; j < nj; ++j) {
+        const TrainJob& tj = jobs[j];
         int K = tj.n + dim_ * tj.ng;
         if (ongpis_eval_class((K + 31) / 32) < 0) {
-            fprintf(stderr, "[gpismap_amd] cluster with K=%d exceeds the supported size (3072)\n", K);
-            return GPIS_ERR_LIMIT;
+            fprintf(stderr, "[gpismap_amd] cluster with K=%d exceeds the supported size (%d): previous model kept\n", K, ONGPIS_MAX_K);
+            if (!deferred_rc) deferred_rc = GPIS_ERR_LIMIT;
+            continue;
         }
         int rc = alloc_model(tj.model, tj.n, tj.ng);
-        if (rc) return rc;
+        if (rc) {
+            ClusterModel& m = models_[tj.model];
+            std::memset(&m, 0, sizeof(ClusterModel));   // untrained; slot stays live
+            dirty_ = true;
+            if (!deferred_rc) deferred_rc = rc;
+            continue;
+        }
+        ok_jobs.push_back(tj);
     }
+    if (ok_jobs.empty()) { int rc0 = sync_models(s); return deferred_rc ? deferred_rc : rc0; }
+    return train_allocated(ok_jobs, ids, s, deferred_rc);
+}
+
+// K6 + kernel build + K3 for jobs whose models are allocated.
+int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc) {
+    const int nj = (int)jobs.size();
+    std::vector<int> tab((size_t)4 * nj);
     // largest clusters first: one workgroup per cluster and K^3 work, so the big factorisations must not start last
     std::vector<int> ord(nj);
     std::iota(ord.begin(), ord.end(), 0);
@@ -181,7 +209,7 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));
     if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
-    return GPIS_OK;
+    return deferred_rc;
 }
 
 // Job-level predict with host job arrays: sort by model, cut into tiles of 8, launch per
@@ -245,7 +273,7 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = 1; a.lds_model = 1;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.lds_model = 1;
         rc = ongpis_eval_launch(c, nt, maxN[c], a, s);
         if (rc) return rc;
     }

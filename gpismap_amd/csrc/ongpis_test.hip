@@ -26,6 +26,15 @@
 
 namespace gpis {
 
+// Timing ablations and the per-wave cycle trace exist only in instrumented builds
+// (make EXTRA=-DGPIS_K4_INSTRUMENT; tools/k4_bench.py): the shipped library has no debug branches in the
+// kernel, reads no environment variables at launch and writes no files.
+#ifdef GPIS_K4_INSTRUMENT
+#define K4_DBG(bits) (A.dbg & (bits))
+#else
+#define K4_DBG(bits) 0
+#endif
+
 // Pointers read out of a ClusterModel live in global memory; say so, otherwise the compiler must
 // emit flat_load (LDS-or-global at run time), which counts on both wait counters.
 typedef const float __attribute__((address_space(1))) * gfptr;
@@ -80,7 +89,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 #define TRACE_OWN() do { if constexpr (TR) { if (trc && lane == 0 && tro < 511) trc[8 * 512 + tro++] = __builtin_readcyclecounter(); } } while (0)
     TRACE();
     if (tid < 32) flags[tid] = -1;
-    if ((A.dbg & 512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
+    if (K4_DBG(512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
         for (int i = 0; i < (A.dbg >> 10); ++i) __builtin_amdgcn_s_sleep(127);
     }
     {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
 
     TRACE();
     // ---- stage 1: exp table, one entry per (training point, query slot) ----
-    if (A.use_table && !(A.dbg & 8)) {
+    if (A.use_table && !K4_DBG(8)) {
         for (int idx = tid; idx < N * 8; idx += 64 * W) {
             int p = idx >> 3, s = idx & 7;
             double e = 0.0;
@@ -204,7 +213,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                 acc[NBW - 1] = t0;
             }
             const int b = wave + W * t;
-            if (b < nb && !(A.dbg & 1)) {
+            if (b < nb && !K4_DBG(1)) {
                 const int r0 = b * 32, r1 = min(K, r0 + 32) - 1;
                 const int k0 = row_type(r0), k1 = row_type(r1);
                 if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), b);
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
                 take_tile(acc[NBW - 1], b);
             }
         }
-        if (A.dbg & 1024) {   // ablation (with dbg & 1): skip the generation but keep non-trivial operand data
+        if (K4_DBG(1024)) {   // ablation (with dbg & 1): skip the generation but keep non-trivial operand data
 #pragma unroll
             for (int t = 0; t < NBW; ++t)
                 if (wave + W * t < nb) {
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
         f32x16 v;
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = 0.f;
-        if (!(A.dbg & 2)) {
+        if (!K4_DBG(2)) {
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], u[kk], v, 0, 0, 0);
         }
@@ -270,14 +279,14 @@ __global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
     };
     // av = -L tile operands (Lt holds the negated factor), vb = V_c in MFMA B-operand order
     auto update_tile = [&](f32x16& a_, const float (&vb)[16], const float (&av)[16]) {
-        if (A.dbg & 4) return;
+        if (K4_DBG(4)) return;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk)
             a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], vb[kk], a_, 0, 0, 0);
     };
     // same, V_c streamed from its LDS ring slot one MFMA pair ahead
     auto update_tile_lds = [&](f32x16& a_, const float* Vl, const float (&av)[16]) {
-        if (A.dbg & 4) return;
+        if (K4_DBG(4)) return;
         float p0 = Vl[0], p1 = Vl[64];
 #pragma unroll
         for (int kk = 0; kk < 16; kk += 2) {
@@ -414,33 +423,36 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
     const int maxLd = kClassNb[wclass] * 32 + 32;
     const size_t budget = 150 * 1024;     // one workgroup must fit; two per CU when <= 80 KB
     args.use_table = 1; args.lds_model = 1;
+    args.dbg = 0; args.trace = nullptr; args.trace_block = 0;
+#ifdef GPIS_K4_INSTRUMENT
     { const char* e = getenv("GPIS_K4_DBG"); args.dbg = e ? atoi(e) : 0; }
     static unsigned long long* d_trace = nullptr;
-    args.trace = nullptr; args.trace_block = 0;
     if (const char* e = getenv("GPIS_K4_TRACE")) {
         if (!d_trace) { (void)hipMalloc(&d_trace, sizeof(unsigned long long) * 512 * 16); }
         (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 16, s);
         args.trace = d_trace; args.trace_block = atoi(e);
     }
+#endif
     size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
     if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
     if (lds > budget) return GPIS_ERR_LIMIT;
-    if (args.use_table && getenv("GPIS_K4_NOTABLE")) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }   // test hook: exercise the large-cluster path
+    if (args.use_table && args_in.use_table == 0) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }   // caller asked for the table-free path (large-cluster path; tests force it)
     typedef void (*kern_t)(EvalArgs);
     static const kern_t kern[ONGPIS_NCLASS] = {
         ongpis_eval_kernel<1, 4, 2, true, false>, ongpis_eval_kernel<2, 4, 2, true, false>,
         ongpis_eval_kernel<4, 4, 2, true, false>, ongpis_eval_kernel<8, 4, 4, false, false>,
         ongpis_eval_kernel<16, 4, 4, false, false>, ongpis_eval_kernel<8, 12, 2, true, false>};
-    static const kern_t kern_tr = ongpis_eval_kernel<8, 4, 4, false, true>;   // traced build of class 3
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
         for (int i = 0; i < ONGPIS_NCLASS; ++i)
             (void)hipFuncSetAttribute((const void*)kern[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    hipLaunchKernelGGL((args.trace && wclass == 3) ? kern_tr : kern[wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
+#ifdef GPIS_K4_INSTRUMENT
+    static const kern_t kern_tr = ongpis_eval_kernel<8, 4, 4, false, true>;   // traced build of class 3
     if (args.trace && wclass == 3) {
+        (void)hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(kern_tr, dim3(ntiles), dim3(64 * W), lds, s, args);
         (void)hipStreamSynchronize(s);
         static unsigned long long h[512 * 16];
         (void)hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost);
@@ -453,7 +465,10 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in
             }
             fclose(f);
         }
+        return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
     }
+#endif
+    hipLaunchKernelGGL(kern[wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
     return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
 }
 

@@ -10,9 +10,9 @@
 //           target vector y = [f; gx; gy; gz], row table.
 //  buildK : lower triangle of K (column-major, ld), y appended as row K so the
 //           forward substitution L z = y falls out of the factorisation.
-//  chol   : right-looking 32-blocked Cholesky in HBM/L2; the trailing update is
-//           v_mfma_f32_32x32x2_f32 (a k-ordered fmaf chain => same bits as the
-//           unblocked chain order), then blocked backward substitution for alpha.
+//  chol   : LEFT-looking 32-blocked Cholesky; the tiles of the current block column live in MFMA
+//           accumulators (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain => same bits as the
+//           unblocked chain order), then blocked backward substitution for alpha (details at K3 below).
 #include "ongpis.h"
 #include "tile_solve.h"
 

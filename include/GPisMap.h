@@ -7,6 +7,17 @@
 #ifndef GPISMAP_AMD_GPISMAP_H_
 #define GPISMAP_AMD_GPISMAP_H_
 
+/* Standard headers the reference's own header exposed to its includers (reference cpp/include/GPisMap.h:23-26 -> ObsGP.h:24-28, OnGPIS.h:24-28, quadtree.h, strct.h
+ * and, through Eigen, <cstring>/<cmath>/<algorithm>): the mex gateways rely on them
+ * (mex/mexGPisMap3.cpp:154 calls memcpy without including <cstring>). */
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <iostream>
+#include <memory>
+#include <unordered_set>
 #include <vector>
 
 typedef struct GPisMapParam_ {

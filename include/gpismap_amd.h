@@ -33,6 +33,11 @@ typedef struct gpis_cam {  /* reference camParam, GPisMap3.h:29-46 */
 /* number of HIP devices visible (0 when no GPU: every compute entry then fails loudly) */
 int gpis_device_count(void);
 const char* gpis_version(void);
+/* Device selection (one process per GPU in a multi-GPU job: call once with LOCAL_RANK before creating anything).
+ * Every object created afterwards lives on the device current at its creation and makes it current inside each
+ * call; d_* pointers and streams handed to *_test_device must belong to that device.  GPIS_ERR_ARG if out of range. */
+int gpis_set_device(int device);
+int gpis_get_device(void);
 
 /* ---- 3-D map (GPisMap3) -------------------------------------------------- */
 void* gpis3_create(const gpis_cam* cam /* NULL = reference defaults */);
@@ -48,6 +53,7 @@ int   gpis3_update(void* map, const float* depth, int n, const float* pose12);
  *                                                             GPisMap3::test GPisMap3.cpp:904 */
 int   gpis3_test(void* map, const float* x, int dim, int n, float* res);
 int   gpis3_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
+int   gpis3_device(void* map);                                 /* device the map lives on, or negative */
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
@@ -66,6 +72,7 @@ int   gpis2_update(void* map, const float* thetas, const float* ranges, int n, c
 /* x: n*2 interleaved; res: n*6 [f gx gy vf vgx vgy], pre-filled by the caller.  GPisMap::test GPisMap.cpp:765 */
 int   gpis2_test(void* map, const float* x, int dim, int n, float* res);
 int   gpis2_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
+int   gpis2_device(void* map);
 int   gpis2_get_nodes(void* map, float* out7, int cap);         /* pos2 grad2 val sigx sigg, tree order */
 int   gpis2_stats(void* map, double* out, int n);               /* same slots as gpis3_stats */
 
@@ -98,6 +105,9 @@ int   gpis_ongpis_get_model(void* s, int model, float* L_ldxld, float* alpha_K, 
  * xq: nq*dim interleaved; out: njobs*8 = mean(4) var(4) (2-D uses 3+3, slots 3 and 7 unused) */
 int   gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs,
                        float* out8);
+/* K4 keeps one double-precision exp per (training point, query) in an LDS table when it fits; clusters too large
+ * for that recompute it per entry.  on = 0 forces the second path for every cluster (results are identical). */
+int   gpis_ongpis_set_exp_table(void* s, int on);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 
 #ifdef __cplusplus

@@ -159,3 +159,24 @@ def test_two_maps_in_one_process_and_caller_stream():
         a.test_device(x.data_ptr(), grid.shape[0], res.data_ptr(), st.cuda_stream)
     st.synchronize()
     assert np.array_equal(res.cpu().numpy().view(np.uint32), r1.view(np.uint32))
+
+
+def test_query_count_growth_reallocates_every_scratch_array():
+    """test() with n = 1, 2, 9 on one map (the second and third calls stay in the same n/8 tile bucket / cross it),
+    then a reset() followed by a LARGER n with fewer models: every size combination must reallocate the tile
+    lists together with the per-query arrays (d_tile_ was freed without resetting its capacity)."""
+    import gpismap_amd
+    frames = replay.load_bigbird()
+    grid = replay.demo3_grid()
+    gm = gpismap_amd.GPisMap3(frames[0]["cam"])
+    om = oracle_lib.OracleMap3(frames[0]["cam"])
+    gm.update(frames[0]["depth"], frames[0]["pose"]); om.update(frames[0]["depth"], frames[0]["pose"])
+    near = grid[np.argsort(np.abs(om.test(grid)[:, 0]))[:4000]]      # queries that do reach clusters
+    for n in (1, 2, 9, 100, 103, 1000, 4000):
+        rg = gm.test(near[:n]); ro = om.test(near[:n])
+        assert np.array_equal(rg, ro), n
+    gm.reset(); om = oracle_lib.OracleMap3(frames[1]["cam"])
+    gm.set_camera(frames[1]["cam"])
+    gm.update(frames[1]["depth"], frames[1]["pose"]); om.update(frames[1]["depth"], frames[1]["pose"])
+    rg = gm.test(grid); ro = om.test(grid)                            # n grows after reset()
+    assert float(np.mean(np.all(rg == ro, axis=1))) >= 0.9995

@@ -94,3 +94,51 @@ def test_obsgp1d_matches_oracle():
         np.testing.assert_array_equal(gx[:n, 0], x)
         assert np.abs(np.tril(gL[:n, :n]) - np.tril(oL.reshape(n, n).T)).max() < 1e-6
         assert np.abs(ga[:n] - oa).max() <= 1e-4 * np.abs(oa).max()
+
+
+def test_obsgp1d_query_kernel_matches_oracle():
+    """1-D obsgp_query at kernel level (ObsGP1D::test ObsGP.cpp:145-187): group selection by the strict
+    (range[j], range[j+1]) intervals, margin 0.0175 at both ends, untouched val / var = 1e6 elsewhere; per-group
+    predictions bit-identical to the oracle's GPou::test."""
+    import gpismap_amd
+    z = np.load(replay.GOLDEN + "/gazebo2d_seq.npz")
+    theta = z["thetas"].astype(np.float32)
+    f = (1.0 / np.sqrt(z["ranges"][3].astype(np.float32))).astype(np.float32)
+    g = gpismap_amd.ObsGP()
+    g.train1d(theta, f)
+    n = theta.shape[0]
+    starts = [20 * i for i in range(12)] + [240, 255]
+    sizes = [26] * 12 + [22, 15]
+    rng_edges = [theta[0]] + [theta[20 * i + 23] for i in range(12)] + [theta[258], theta[n - 1]]
+    rng = np.random.default_rng(11)
+    q = np.concatenate([
+        rng.uniform(theta[0] - 0.05, theta[-1] + 0.05, 3000).astype(np.float32),
+        np.array(rng_edges, dtype=np.float32),                                  # exactly on a boundary: no group answers
+        np.array([theta[0] + np.float32(0.0175), theta[-1] - np.float32(0.0175)], dtype=np.float32),
+        theta[::7]]).astype(np.float32)
+    val, var = g.query(q, val0=-7.0)
+    L_ = oracle_lib.lib()
+    liml = np.float32(rng_edges[0]) + np.float32(0.0175)
+    limr = np.float32(rng_edges[-1]) - np.float32(0.0175)
+    oval = np.full(q.shape, np.float32(-7.0), dtype=np.float32)
+    ovar = np.full(q.shape, np.float32(1e6), dtype=np.float32)
+    for k, x in enumerate(q):
+        if x < liml or x > limr:
+            continue
+        for j in range(14):
+            if x > rng_edges[j] and x < rng_edges[j + 1]:
+                a, m = starts[j], sizes[j]
+                xs = np.ascontiguousarray(theta[a:a + m]); fs = np.ascontiguousarray(f[a:a + m])
+                v = np.zeros(1, dtype=np.float32); r = np.zeros(1, dtype=np.float32)
+                xq = np.array([x], dtype=np.float32)
+                L_.orc_gpou_test(oracle_lib._p(xs), oracle_lib._p(fs), 1, m, oracle_lib._p(xq), 1, oracle_lib._p(v), oracle_lib._p(r))
+                oval[k], ovar[k] = v[0], r[0]
+                break
+    hit = ovar < 1e5
+    assert hit.sum() > 2500 and (~hit).sum() > 20
+    assert np.array_equal(hit, var < 1e5)
+    assert np.array_equal(val[~hit], oval[~hit]) and np.all(var[~hit] == np.float32(1e6))
+    same = float(np.mean((val[hit] == oval[hit]) & (var[hit] == ovar[hit])))
+    print("1-D queries %d answered %d bit-identical %.6f" % (q.shape[0], int(hit.sum()), same))
+    assert same >= 0.9995
+    assert np.abs(val[hit] - oval[hit]).max() < 1e-5 and np.abs(var[hit] - ovar[hit]).max() < 1e-5

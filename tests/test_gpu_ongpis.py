@@ -130,9 +130,9 @@ def test_size_class_boundaries(n):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
-def test_predict_without_exp_table_is_identical(monkeypatch):
+def test_predict_without_exp_table_is_identical():
     """Clusters too large for the per-tile exp table in LDS take a path that evaluates exp() per kernel
-    entry (GPIS_K4_NOTABLE forces it): results must not change by a bit."""
+    entry (gpis_ongpis_set_exp_table(0) forces it): results must not change by a bit."""
     import gpismap_amd
     dim, scale = 3, 0.04
     rng = np.random.default_rng(77)
@@ -151,7 +151,7 @@ def test_predict_without_exp_table_is_identical(monkeypatch):
     jq = np.arange(xq.shape[0], dtype=np.int32)
     jm = np.repeat(models, nq).astype(np.int32)
     with_table = st.eval(xq, jq, jm).copy()
-    monkeypatch.setenv("GPIS_K4_NOTABLE", "1")
+    st.set_exp_table(False)
     without = st.eval(xq, jq, jm)
     assert np.array_equal(with_table.view(np.uint32), without.view(np.uint32))
 
