@@ -221,9 +221,8 @@ __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restri
     for (int m = m0; m < m1; ++m) {
         int c = cnt[m];
         if (c > 0) {
-            int nb = models[m].nb;
-            int cls = ongpis_class_of_nb(nb);
-            aj += c; at[cls] += (c + 7) / 8;
+            int cls = ongpis_class_of_nbx(models[m].ld >> 5);
+            aj += c; at[cls] += (c + ONGPIS_TILE_Q - 1) / ONGPIS_TILE_Q;
             // algorithmic flops of one evaluation: (1+d) K^2 + 2 (1+d) K + 25 N
             unsigned long long K = models[m].K, N = models[m].N, d1 = 1 + models[m].dim;
             af += (unsigned long long)c * (d1 * K * K + 2 * d1 * K + 25 * N);
@@ -252,10 +251,9 @@ __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restri
         int c = cnt[m];
         base[m] = rj; cursor[m] = 0;
         if (c > 0) {
-            int nb = models[m].nb;
-            int cls = ongpis_class_of_nb(nb);
+            int cls = ongpis_class_of_nbx(models[m].ld >> 5);
             tbase[m] = rt[cls];
-            rt[cls] += (c + 7) / 8;
+            rt[cls] += (c + ONGPIS_TILE_Q - 1) / ONGPIS_TILE_Q;
             rj += c;
         } else tbase[m] = 0;
     }
@@ -281,14 +279,13 @@ __global__ void tiles_kernel(const ClusterModel* __restrict__ models, int nmodel
     int m = blockIdx.x;
     int c = cnt[m];
     if (c <= 0) return;
-    int nb = models[m].nb;
-    int cls = ongpis_class_of_nb(nb);
+    int cls = ongpis_class_of_nbx(models[m].ld >> 5);
     int t0 = tot[8 + cls] + tbase[m];
-    int nt = (c + 7) / 8;
+    int nt = (c + ONGPIS_TILE_Q - 1) / ONGPIS_TILE_Q;
     for (int i = threadIdx.x; i < nt; i += blockDim.x) {
         tile_model[t0 + i] = m;
-        tile_off[t0 + i] = base[m] + 8 * i;
-        tile_cnt[t0 + i] = min(8, c - 8 * i);
+        tile_off[t0 + i] = base[m] + ONGPIS_TILE_Q * i;
+        tile_cnt[t0 + i] = min(ONGPIS_TILE_Q, c - ONGPIS_TILE_Q * i);
     }
 }
 
@@ -349,7 +346,7 @@ __global__ void prior_only_kernel(int n, int nc2, int vidx, float prior_var, flo
 
 // --------------------------------------------------------------- host side ----
 MapQuery::MapQuery(int dim, float search_half, float var_thre, float prior_var)
-    : dim_(dim), search_half_(search_half), var_thre_(var_thre), prior_var_(prior_var), h_maxN_(ONGPIS_NCLASS, 0) {
+    : dim_(dim), search_half_(search_half), var_thre_(var_thre), prior_var_(prior_var), h_maxN_(ONGPIS_NCLASS, 0), h_maxLd_(ONGPIS_NCLASS, 0) {
     std::memset(&tv_, 0, sizeof(tv_));
 }
 
@@ -441,7 +438,7 @@ int MapQuery::ensure_scratch(int n, int nmodels) {
         GPIS_HIP(hipMalloc(&d_out_, sizeof(float) * 8 * 3 * c));
         cap_n_ = n;
     }
-    int need_tiles = 2 * (cap_n_ / 8 + 1) + nmodels + 64;
+    int need_tiles = 2 * (cap_n_ / ONGPIS_TILE_Q + 1) + nmodels + 64;
     if (need_tiles > tile_cap_) {
         (void)hipFree(d_tile_); d_tile_ = nullptr;
         GPIS_HIP(hipMalloc(&d_tile_, sizeof(int) * 3 * (size_t)need_tiles));
@@ -500,8 +497,8 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
         EvalArgs a;
         a.models = store.d_models(); a.xq = d_xq_;
         a.tile_model = t_model + tot[8 + c]; a.tile_off = t_off + tot[8 + c]; a.tile_cnt = t_cnt + tot[8 + c];
-        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.lds_model = 1;
-        int rc = ongpis_eval_launch(c, nt, h_maxN_[c], a, s);
+        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        int rc = ongpis_eval_launch(c, nt, h_maxN_[c], h_maxLd_[c], a, s);
         if (rc) return rc;
     }
     if (profile) {
@@ -547,11 +544,13 @@ int MapQuery::run(OnGPISStore& store, const float* d_x, int n, float* d_res, hip
     if (rc) return rc;
     // per-class max N (LDS sizing of K4)
     std::fill(h_maxN_.begin(), h_maxN_.end(), 0);
+    std::fill(h_maxLd_.begin(), h_maxLd_.end(), 0);
     for (int i = 0; i < store.num_slots(); ++i) {
         const ClusterModel* m = store.model(i);
         if (!m || !m->base) continue;
-        int c = ongpis_eval_class(m->nb);
-        if (c >= 0) h_maxN_[c] = std::max(h_maxN_[c], m->N);
+        int c = ongpis_eval_class(m->ld / 32);
+        h_maxN_[c] = std::max(h_maxN_[c], m->N);
+        h_maxLd_[c] = std::max(h_maxLd_[c], m->ld);
     }
     const int nc = 2 * (1 + dim_);
     if (ncl_ == 0) {  // no cluster anywhere: only the prior variance is written

@@ -24,6 +24,11 @@ struct ClusterModel {
                             // [g][lane][j] = T[lane & 31][k(4g + j, lane >> 5)].  Off-diagonal tile (b, c): T = -L_bc,
                             // k(kk, h) = 2 kk + h.  Diagonal tile (c, c): T = inv(L_cc) (identity-padded),
                             // k(kk, h) = (kk & 3) + 8 (kk >> 2) + 4 h, the row of an accumulator tile register.
+    float* Xt;              // explicit inverse X = L^-1 re-tiled for K4 (written by K3b): same tile indexing as Lt, every tile
+                            // (b, c), c <= b, in NATURAL A-operand order [g][lane][j] = X_bc[lane & 31][2 (4g + j) + (lane >> 5)];
+                            // row K of X (block row ld/32 - 1) carries alpha, so that row K of V = X k* is the mean k*^T alpha
+    float* Zt;              // the transposed tiles (X_bc)^T in the same order at the same index: what K3b's own recurrence
+                            // feeds to the matrix cores as the B operand
     float* alpha;           // [ld]
     float* x4;              // [N][4]  (x, y, z|0, 0)
     int* rowinfo;           // [ld] row -> point | comp<<28 (comp 0 = value row, 1..dim = d/dx_c)
@@ -90,6 +95,7 @@ private:
     PointsSoA pts_;
     int* d_ids_ = nullptr; int cap_ids_ = 0;
     int* d_jobs_ = nullptr; int cap_jobs_ = 0;   // train job table (4 ints per job)
+    int* d_work_ = nullptr; int cap_work_ = 0;   // K3b work list (job, block column)
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipStream_t s2_ = nullptr;                   // side stream: small factorisations run beside the large ones
@@ -101,30 +107,33 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
+// K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nwork, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;
     const float4* xq;        // [nq] query points (x, y, z|0, 0)
     const int* tile_model;   // [ntiles]
     const int* tile_off;     // [ntiles] first job of the tile in job_q / job_out
-    const int* tile_cnt;     // [ntiles] 1..8
+    const int* tile_cnt;     // [ntiles] 1..ONGPIS_TILE_Q
     const int* job_q;        // query index per job (sorted by model)
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
-    int use_table;           // exp table in LDS (else recompute per entry)
-    int lds_model;           // alpha / rowinfo / x4 staged in LDS (set by ongpis_eval_launch)
-    unsigned long long* trace;  // optional per-wave cycle trace of workgroup `trace_block` (env GPIS_K4_TRACE)
-    int trace_block;
-    int dbg;                 // timing ablations (env GPIS_K4_DBG; results are wrong when non-zero)
+    int use_table;           // exp table in LDS (else recompute per entry); the launcher clears it when the table does not fit
+    int cb;                  // column blocks per B chunk (set by ongpis_eval_launch from the LDS budget)
+    int nslot;               // chunks in the LDS ring (2 or 3)
+    unsigned long long* trace;   // instrumented builds only (tools/k4_ablate.sh); nullptr otherwise
 };
-// K4 size classes by nb = ceil(K/32): 0: nb<=4 (1 wave x 4 tiles), 1: <=8 (2x4), 2: <=16 (4x4),
-// 3: <=32 (8x4), 4: <=64 (16x4), 5: <=96 (8x12); -1 -> cluster too large for this build (K > 3072)
-#define ONGPIS_NCLASS 6
-#define ONGPIS_MAX_K 3072
-__host__ __device__ inline int ongpis_class_of_nb(int nb) {
-    return nb <= 4 ? 0 : (nb <= 8 ? 1 : (nb <= 16 ? 2 : (nb <= 32 ? 3 : (nb <= 64 ? 4 : 5))));
-}
-int ongpis_eval_class(int nb);
-int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args, hipStream_t s);
+// K4 size classes by nbx = ld / 32 = ceil((K+1)/32) block rows: W = 1, 2, 4, 8 wavefronts per workgroup for
+// nbx <= 4, 8, 16, more (no upper limit: large clusters run several row groups).
+#define ONGPIS_NCLASS 4
+#ifndef K4_QS
+#define K4_QS 1   // measured on the 256^3 bench: 1 set / 128 VGPRs / 2 workgroups per CU 811 ms, 2 sets / 256 VGPRs / 1 per CU 870 ms
+#endif
+#define ONGPIS_TILE_Q (8 * K4_QS)   // queries per K4 workgroup (K4_QS sets of 8 sharing every X tile)
+#define ONGPIS_MAX_K 16384   // allocation sanity bound only (10 K^2 bytes per model)
+__host__ __device__ inline int ongpis_class_of_nbx(int nbx) { return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= 16 ? 2 : 3)); }
+int ongpis_eval_class(int nbx);
+int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 
 }  // namespace gpis

@@ -14,7 +14,7 @@ OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_
 
 OnGPISStore::~OnGPISStore() {
     clear();
-    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_ej_);
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_ej_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (evf_) (void)hipEventDestroy(evf_);
@@ -64,7 +64,8 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
     int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     size_t oT = align_up(oG + szG, 256), szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
-    size_t total = align_up(oT + szT, 256);
+    size_t oXt = align_up(oT + szT, 256), oZt = align_up(oXt + szT, 256);   // explicit inverse, re-tiled, and its transposed tiles
+    size_t total = align_up(oZt + szT, 256);
     if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
     char* base = (char*)pool_alloc(pool_, total);
     if (!base) return GPIS_ERR_HIP;
@@ -72,6 +73,7 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
     m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
     m.Lt = (float*)(base + oT);
+    m.Xt = (float*)(base + oXt); m.Zt = (float*)(base + oZt);
     m.base = base;
     dirty_ = true;
     return GPIS_OK;
@@ -129,7 +131,7 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     for (int j = 0; j < nj; ++j) {
         const TrainJob& tj = jobs[j];
         int K = tj.n + dim_ * tj.ng;
-        if (ongpis_eval_class((K + 31) / 32) < 0) {
+        if (K > ONGPIS_MAX_K) {
             fprintf(stderr, "[gpismap_amd] cluster with K=%d exceeds the supported size (%d): previous model kept\n", K, ONGPIS_MAX_K);
             if (!deferred_rc) deferred_rc = GPIS_ERR_LIMIT;
             continue;
@@ -175,8 +177,21 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         GPIS_HIP(hipMalloc(&d_jobs_, sizeof(int) * (size_t)cap));
         cap_jobs_ = cap;
     }
+    // K3b work list: one wavefront per (job, block column), big clusters and long columns first
+    std::vector<int> work;
+    for (int j = 0; j < nj; ++j) {
+        const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+        for (int c = 0; c < nbj; ++c) { work.push_back(j); work.push_back(c); }
+    }
+    if ((int)work.size() > cap_work_) {
+        (void)hipFree(d_work_); d_work_ = nullptr;
+        int cap = (int)work.size() * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_work_, sizeof(int) * (size_t)cap));
+        cap_work_ = cap;
+    }
     GPIS_HIP(hipMemcpyAsync(d_ids_, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
     if (profile) {
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
@@ -205,6 +220,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         GPIS_HIP(hipEventRecord(evj_, s2_));
         GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
     }
+    ongpis_launch_inverse(d_models_, d_jobs_, d_work_, (int)work.size() / 2, s);   // K3b: X = L^-1, re-tiled for K4
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));
@@ -212,7 +228,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     return deferred_rc;
 }
 
-// Job-level predict with host job arrays: sort by model, cut into tiles of 8, launch per
+// Job-level predict with host job arrays: sort by model, cut into tiles of ONGPIS_TILE_Q (16), launch per
 // size class.  (The map-level test path bins on the device instead, see map_query.hip.)
 int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
                            hipStream_t s) {
@@ -224,19 +240,18 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h_job_model[a] < h_job_model[b]; });
     std::vector<int> jq(njobs), jo(njobs);
     std::vector<int> tmodel[ONGPIS_NCLASS], toff[ONGPIS_NCLASS], tcnt[ONGPIS_NCLASS];
-    int maxN[ONGPIS_NCLASS] = {0};
+    int maxN[ONGPIS_NCLASS] = {0}, maxLd[ONGPIS_NCLASS] = {0};
     for (int i = 0; i < njobs;) {
         int mslot = h_job_model[order[i]];
         const ClusterModel* m = model(mslot);
         if (!m || !m->base) return GPIS_ERR_ARG;
-        int cls = ongpis_eval_class(m->nb);
-        if (cls < 0) return GPIS_ERR_LIMIT;
+        int cls = ongpis_eval_class(m->ld / 32);
         int e = i;
         while (e < njobs && h_job_model[order[e]] == mslot) ++e;
-        for (int t = i; t < e; t += 8) {
-            tmodel[cls].push_back(mslot); toff[cls].push_back(t); tcnt[cls].push_back(std::min(8, e - t));
+        for (int t = i; t < e; t += ONGPIS_TILE_Q) {
+            tmodel[cls].push_back(mslot); toff[cls].push_back(t); tcnt[cls].push_back(std::min(ONGPIS_TILE_Q, e - t));
         }
-        maxN[cls] = std::max(maxN[cls], m->N);
+        maxN[cls] = std::max(maxN[cls], m->N); maxLd[cls] = std::max(maxLd[cls], m->ld);
         for (int t = i; t < e; ++t) { jq[t] = h_job_q[order[t]]; jo[t] = order[t]; }
         i = e;
     }
@@ -273,8 +288,8 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.lds_model = 1;
-        rc = ongpis_eval_launch(c, nt, maxN[c], a, s);
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        rc = ongpis_eval_launch(c, nt, maxN[c], maxLd[c], a, s);
         if (rc) return rc;
     }
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));

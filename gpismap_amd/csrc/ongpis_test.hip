@@ -7,17 +7,21 @@
 //        -> matern32_sparse_deriv1_3D (cross)  cpp/src/covFnc.cpp:258-314 (2-D: :404-450)
 //        -> k*^T alpha ; L^-1 k* ; column sums of squares
 //
-// Work decomposition.  The (1+d) cross-covariance columns of 8 queries form a
-// K x 32 right-hand-side block B.  One workgroup of W wavefronts solves
-// L V = B by a right-looking 32-blocked forward substitution:
-//   * block row b of B lives in the accumulator registers of wave (b mod W)
-//     for the whole solve (f32x16 per 32x32 tile, MFMA C/D layout);
-//   * step c: the owner of block c multiplies its tile by the inverted diagonal block
-//     (V_c = inv(L_cc) U_c, 16 matrix instructions; the inverse comes from K3) and publishes V_c to LDS;
-//   * every wave then applies  B_b -= L_bc V_c  to its tiles with
-//     v_mfma_f32_32x32x2_f32, streaming L_bc from L2/HBM exactly once.
-// Each L element is read once per workgroup and used for 32 columns.  The
-// per-element operation order is the ascending-k fmaf chain of dev_common.h.
+// Work decomposition.  The (1+d) cross-covariance columns of 8 queries form a K x 32 right-hand-side
+// block B.  The reference solves L V = B by substitution -- a chain of K dependent steps.  Here the
+// factor's explicit inverse X = L^-1 comes out of training (K3b, ongpis_train.hip), so
+//     V = X B      (lower-triangular matrix product, 32 x 32 tiles, v_mfma_f32_32x32x2_f32)
+// has NO dependency between its block rows: every wavefront of the workgroup owns a few block rows
+// (accumulators in registers), streams the X tiles of those rows from L2/HBM exactly once and reads the
+// B tiles all wavefronts share from LDS.  alpha rides along as row K of X, so row K of V is the mean
+// k*^T alpha (one ascending fmaf chain) and needs no separate reduction.
+//   * B is generated in chunks of CB column blocks into a double-buffered LDS ring: half of the
+//     wavefronts generate chunk i+1 before multiplying chunk i, the other half after -- on every SIMD one
+//     wavefront feeds the vector ALU while the other feeds the matrix pipe.  One barrier per chunk.
+//   * block rows are dealt to the wavefronts from the largest down, snake-wise (row b costs b+1 tile
+//     products); clusters with more than 4 W block rows run several row groups (B chunks are regenerated
+//     for the later, cheaper groups), so there is no upper limit on K.
+// Per element V[r][j] is ONE fmaf chain from zero over ascending k -- the order of the oracle's tiled mode.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -26,455 +30,409 @@
 
 namespace gpis {
 
-// Timing ablations and the per-wave cycle trace exist only in instrumented builds
-// (make EXTRA=-DGPIS_K4_INSTRUMENT; tools/k4_bench.py): the shipped library has no debug branches in the
-// kernel, reads no environment variables at launch and writes no files.
-#ifdef GPIS_K4_INSTRUMENT
-#define K4_DBG(bits) (A.dbg & (bits))
-#else
-#define K4_DBG(bits) 0
-#endif
-
 // Pointers read out of a ClusterModel live in global memory; say so, otherwise the compiler must
 // emit flat_load (LDS-or-global at run time), which counts on both wait counters.
 typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const int __attribute__((address_space(1))) * giptr;
-typedef const float4 __attribute__((address_space(1))) * gf4ptr;
-typedef const void __attribute__((address_space(1))) * gvptr;
-typedef float __attribute__((address_space(3))) * lds_fptr;
-typedef void __attribute__((address_space(3))) * lds_vptr;
+
+// Ablation builds for tools/k4_ablate.sh only (-DK4X=<bits>; results are WRONG when set): 1 = generate only the
+// first chunks (prologue), 16 = one X tile load per row and chunk, 32 = B operands from registers (no LDS reads), 4 / 8 unused
+#ifndef K4X
+#define K4X 0
+#endif
+#ifndef K4_MINW
+#define K4_MINW (K4_QS == 1 ? 4 : 2)   // wavefronts per SIMD the register budget is cut for (128 / 256 VGPRs)
+#endif
+#ifndef K4_SYNC_BARRIER
+#define K4_SYNC_BARRIER 1   // 1: one workgroup barrier per chunk; 0: per-wave ready/done flags in LDS (no barrier)
+#endif
+
+constexpr int kTileStride = 36;                 // floats per row of a B tile in LDS (conflict-free 16-byte row writes AND operand reads)
+constexpr int kTileFloats = 32 * kTileStride;   // 1152
+
 typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // explicit LDS: volatile generic pointers become flat loads
 
-
-// Size classes (block rows nb = ceil(K/32)): W waves x NBW tiles per wave.
-//   nb <= 4: 1x4   <= 8: 2x4   <= 16: 4x4   <= 32: 8x4 (128 VGPRs)   <= 64: 16x4 (128 VGPRs)   <= 96: 8x12
-// VREG: V_c is read into registers once per step (256-VGPR classes) or streamed from LDS per MFMA pair
-// (128-VGPR classes, four waves per SIMD).  TR: cycle-trace build of the kernel (GPIS_K4_TRACE).
-template <int W, int NBW, int MINW, bool VREG, bool TR>
-__global__ __launch_bounds__(64 * W, MINW) void ongpis_eval_kernel(EvalArgs A) {
-    constexpr int RING = 4;   // published V blocks / diagonal blocks kept in LDS
+// W wavefronts, NBW block rows per wavefront and row group, QS query sets of 8 per workgroup (every X tile feeds QS
+// tile products)
+template <int W, bool TABLE, int QS, int NBW>
+__global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A) {
+    constexpr int RG = NBW * W;   // block rows per row group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the ownership logic in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the row ownership logic in SGPRs
     const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel m = A.models[A.tile_model[tile]];
-    const int N = m.N, K = m.K, ld = m.ld, nb = m.nb, dim = m.dim;
-    const int joff = A.tile_off[tile], jcnt = A.tile_cnt[tile];
-
-    // LDS carve (all dynamic, 16-byte aligned pieces).  Region U is time-shared: stage 1/2 keep the
-    // per-lane staging strips and the exp table there, stage 3 the ring of published V blocks.
-    float* red = reinterpret_cast<float*>(smem);                  // [W][64][2]
-    lds_flag_ptr flags = (lds_flag_ptr)(red + W * 128);           // [0] = pub, [1..W] = done[w]; 32 ints reserved
-    float* s_alpha = red + W * 128 + 32;                          // [ld]
-    int* s_ri = reinterpret_cast<int*>(s_alpha + ld);             // [ld]
-    float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);          // [N]   (ld is a multiple of 32 -> 16-B aligned)
-    float* U = reinterpret_cast<float*>(s_x4 + N);
-    float* stage = U;                                             // stage 2: [W][32*36] per-wave padded tile
-    double* etab = reinterpret_cast<double*>(U + W * 1152);       // stage 1/2: [N][8] exp table (optional)
-    float* Vbuf = U;                                              // stage 3: [RING][32*32] published V blocks
-
-    const float a = (float)(sqrt(3.0) / (double)m.scale);
-
-    // this lane's column: query slot qi, component cq
-    const int qi = l31 >> 2, cq = l31 & 3;
-    const bool qact = (qi < jcnt) && (cq <= dim);
-
-    // optional cycle trace of one workgroup (A.trace != nullptr): [wave][slot] timestamps
-    unsigned long long* trc = (TR && A.trace && (int)blockIdx.x == A.trace_block) ? A.trace + wave * 512 : nullptr;
+    const ClusterModel* __restrict__ mp = A.models + A.tile_model[tile];   // only the fields needed are read (scalar loads)
+    const int N = mp->N, K = mp->K, ld = mp->ld, nb = mp->nb, dim = mp->dim;
+    const int nbx = ld >> 5;      // block rows of V: ceil((K+1)/32), row K = mean
+    const int joff = A.tile_off[tile], jcnt = A.tile_cnt[tile];   // 1..16 queries
+    const int nset = (QS == 2 && jcnt > 8) ? 2 : 1;
+    const int CB = A.cb, NSLOT = A.nslot;
+#if K4X & 64
+    unsigned long long* trc = (A.trace && blockIdx.x % 997 == 0 && blockIdx.x / 997 < 64) ? A.trace + (blockIdx.x / 997) * 64 + wave * 8 : nullptr;
     int tri = 0;
-#define TRACE() do { if constexpr (TR) { if (trc && lane == 0 && tri < 512) trc[tri++] = __builtin_readcyclecounter(); } } while (0)
-    // owner-path events (traced build): [8 + wave][slot]
-    int tro = 0;
-#define TRACE_OWN() do { if constexpr (TR) { if (trc && lane == 0 && tro < 511) trc[8 * 512 + tro++] = __builtin_readcyclecounter(); } } while (0)
-    TRACE();
-    if (tid < 32) flags[tid] = -1;
-    if (K4_DBG(512) && (blockIdx.x & 1)) {  // experiment: stagger the two workgroups sharing a CU
-        for (int i = 0; i < (A.dbg >> 10); ++i) __builtin_amdgcn_s_sleep(127);
-    }
-    {   // stage 0: per-cluster vectors into LDS with coalesced loads (always fits for K <= 3072)
-        gfptr g_alpha = (gfptr)m.alpha;
-        giptr g_ri = (giptr)m.rowinfo;
-        gfptr g_x4 = (gfptr)m.x4;
-        for (int i = tid; i < ld; i += 64 * W) { s_alpha[i] = g_alpha[i]; s_ri[i] = g_ri[i]; }
+#define K4_STAMP() do { if (trc && lane == 0 && tri < 8) trc[tri++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define K4_STAMP() do {} while (0)
+#endif
+    K4_STAMP();
+
+    // LDS carve (all dynamic, 16-byte aligned pieces)
+    constexpr int NC = 32 * QS;   // result columns of the workgroup
+    constexpr int ES = 8 * QS + 1;  // doubles per point in the exp table: odd stride -> conflict-free 8-byte reads across points
+    float* red = reinterpret_cast<float*>(smem);                       // [W][NC] sums of squares, then [NC] means
+    float4* s_xq = reinterpret_cast<float4*>(red + W * NC + NC);       // [16] the tile's query points
+    lds_flag_ptr flags = (lds_flag_ptr)(s_xq + 16);                    // rdyw[W] then donew[W]; 32 ints reserved
+    int* s_ri = reinterpret_cast<int*>(s_xq + 16) + 32;                // [ld] row -> point | component
+    float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
+    double* etab = reinterpret_cast<double*>(s_x4 + N);                // [N][16] exp table (optional)
+    float* Bbuf = reinterpret_cast<float*>(etab + (TABLE ? (((size_t)N * ES + 1) & ~(size_t)1) : 0));   // [NSLOT][CB][QS][32*36]
+    lds_flag_ptr rdyw = flags, donew = flags + W;
+
+    const float scale = mp->scale;
+    const float a = (float)(sqrt(3.0) / (double)scale);
+
+    {   // stage 0: per-cluster vectors and the queries into LDS with coalesced loads
+        giptr g_ri = (giptr)mp->rowinfo;
+        gfptr g_x4 = (gfptr)mp->x4;
+        for (int i = tid; i < ld; i += 64 * W) s_ri[i] = g_ri[i];
         for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
+        if (tid < 16) s_xq[tid] = (tid < jcnt) ? A.xq[A.job_q[joff + tid]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 32) flags[tid] = -1;
         __syncthreads();
     }
+    K4_STAMP();
     const float4* x4 = s_x4;
-    // off-diagonal tiles come from the re-tiled copy Lt (-L, MFMA A-operand order) through a buffer resource:
-    // one VGPR byte offset per lane + scalar offsets, 4 x 16-byte loads per tile
-    const int ntl = nb * (nb + 1) / 2;
-    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    // X tiles (A-operand order, 4 x 16-byte loads per tile) through a buffer resource: one VGPR byte offset per
+    // lane + scalar tile offsets
+    const int ntl = nbx * (nbx + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Xrs = __builtin_amdgcn_make_buffer_rsrc((void*)mp->Xt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
 
-    TRACE();
     // ---- stage 1: exp table, one entry per (training point, query slot) ----
-    if (A.use_table && !K4_DBG(8)) {
-        for (int idx = tid; idx < N * 8; idx += 64 * W) {
-            int p = idx >> 3, s = idx & 7;
+    if (TABLE) {
+        for (int idx = tid; idx < N * 8 * QS; idx += 64 * W) {
+            const int p = idx / (8 * QS), s = idx % (8 * QS);
             double e = 0.0;
             if (s < jcnt) {
-                float4 xp = x4[p];
-                float4 q = A.xq[A.job_q[joff + s]];
-                float d0 = xp.x - q.x, d1 = xp.y - q.y, d2 = xp.z - q.z;
-                float r = (dim == 3) ? sqrtf((d0 * d0 + d1 * d1) + d2 * d2) : sqrtf(d0 * d0 + d1 * d1);
+                const float4 xp = x4[p];
+                const float4 q = s_xq[s];
+                const float d0 = xp.x - q.x, d1 = xp.y - q.y, d2 = xp.z - q.z;
+                const float r = (dim == 3) ? sqrtf((d0 * d0 + d1 * d1) + d2 * d2) : sqrtf(d0 * d0 + d1 * d1);
                 e = exp((double)(-a * r));
             }
-            etab[idx] = e;
+            etab[p * ES + s] = e;
         }
+        __syncthreads();
     }
-    __syncthreads();
 
-    TRACE();
-    // ---- stage 2: B tiles into accumulators + partial means ----
-    // Cooperative generation: lane (r, qh) produces the 16 entries of tile row r for the queries
-    // 4qh..4qh+3 (distance, exp-table lookup and coefficient set-up shared by the 4 components),
-    // writes them to a padded per-wave LDS tile, which is then read back in MFMA C/D layout.
-    f32x16 acc[NBW];
-    float mp = 0.f;  // partial k*^T alpha over this lane's rows (order O3)
-    float* tbuf = stage + wave * (32 * 36);   // [32 rows][36] (stride 36 floats: conflict-free 16-byte writes)
-    {
+    K4_STAMP();
+    // ---- generation of one B tile (column block c, query set qs) into an LDS tile: lane (r, qh) produces the 16
+    // entries of tile row r for the queries 4qh..4qh+3 of the set (distance, exp-table lookup and coefficient set-up
+    // shared by the 4 components) and writes them as four 16-byte stores.  KIND = row type of the whole tile when it
+    // is uniform (0: value rows, 1..3: d/dx_c rows -- the rows are ordered by type, so almost every tile is uniform
+    // and the type selects of covFnc.cpp:292-308 fold away), -1: mixed tile, per-row type.
+    const int ngr = (dim > 0) ? (K - N) / dim : 0;   // rows per derivative component
+    auto row_type = [&](int r) { return r < N ? 0 : 1 + (r - N) / (ngr > 0 ? ngr : 1); };
+    auto emit_rows = [&](auto kind_tag, int c, int qs, float* tbuf) {
+        constexpr int KIND = decltype(kind_tag)::value;
         const int rr_ = lane & 31, qh = lane >> 5;
-        float4 xqs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int q = 4 * qh + j;
-            xqs[j] = (q < jcnt) ? A.xq[A.job_q[joff + q]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int row = c * 32 + rr_;
+        float4* trow = reinterpret_cast<float4*>(tbuf + rr_ * kTileStride + 16 * qh);
+        int p = 0, cr = 0;
+        float4 xp = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < K) {
+            const int info = s_ri[row];
+            p = info & 0x0FFFFFFF;
+            cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
+            xp = x4[p];
         }
-        // The 16 entries of one (row, 4 queries) strip.  KIND = row type of the whole tile when it is uniform
-        // (0: value rows, 1..3: d/dx_c rows -- the rows are ordered by type, so almost every tile is uniform and
-        // the compiler folds the type selects of covFnc.cpp:292-308 away), -1: mixed tile, per-row type.
-        auto emit_rows = [&](auto kind_tag, int b) {
-            constexpr int KIND = decltype(kind_tag)::value;
-            const int row = b * 32 + rr_;
-            float4 out[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) out[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < K) {
-                const int info = s_ri[row];
-                const int p = info & 0x0FFFFFFF;
-                const int cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
-                const float4 xp = x4[p];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int q = 4 * qh + j;
-                    if (q < jcnt) {
-                        float d[3] = {xp.x - xqs[j].x, xp.y - xqs[j].y, xp.z - xqs[j].z};
-                        float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
-                        double e = A.use_table ? etab[p * 8 + q] : exp((double)(-a * rr));
-                        float v0, v1, v2, v3;
-                        if (cr == 0) {
-                            v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
-                        } else {
-                            const float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
-                            v0 = -d_kf1(dr, a, e);
-                            // mixed second derivatives: lower component first (covFnc.cpp:300-308)
-                            v1 = (cr == 1) ? d_kf2(rr, d[0], d[0], 1.0f, a, e) : d_kf2(rr, d[0], dr, 0.0f, a, e);
-                            v2 = (cr == 2) ? d_kf2(rr, d[1], d[1], 1.0f, a, e)
-                                           : (cr == 1 ? d_kf2(rr, d[0], d[1], 0.0f, a, e) : d_kf2(rr, d[1], d[2], 0.0f, a, e));
-                            v3 = (cr == 3) ? d_kf2(rr, d[2], d[2], 1.0f, a, e) : d_kf2(rr, dr, d[2], 0.0f, a, e);
-                        }
-                        if (dim == 2) v3 = 0.f;
-                        out[j] = make_float4(v0, v1, v2, v3);
-                    }
-                }
-            }
-            float4* trow = reinterpret_cast<float4*>(tbuf + rr_ * 36 + 16 * qh);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) trow[j] = out[j];
-        };
-        // padded LDS strip -> accumulator tile t (static register index) + partial means
-        auto take_tile = [&](f32x16& tl, int b) {
-            __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): this wave's LDS writes have landed
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rw = rowmap_t(r, h);
-                const float v = tbuf[rw * 36 + l31];
-                tl[r] = v;
-                mp = fmaf(v, s_alpha[b * 32 + rw], mp);   // rows >= K: B = 0 and alpha = 0 (K3 pads)
-            }
-            __builtin_amdgcn_wave_barrier();
-        };
-        const int ngr = (dim > 0) ? (K - N) / dim : 0;   // rows per derivative component
-        auto row_type = [&](int r) { return r < N ? 0 : 1 + (r - N) / (ngr > 0 ? ngr : 1); };
-#pragma unroll
-        for (int t = 0; t < NBW; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 #pragma unroll 1
-        for (int t = 0; t < NBW; ++t) {
-            // The evaluation code exists once: every tile is generated into the LAST register tile after a rotation
-            // by one place; after NBW trips each tile sits in its home position.
-            {
-                const f32x16 t0 = acc[0];
-#pragma unroll
-                for (int u = 0; u + 1 < NBW; ++u) acc[u] = acc[u + 1];
-                acc[NBW - 1] = t0;
-            }
-            const int b = wave + W * t;
-            if (b < nb && !K4_DBG(1)) {
-                const int r0 = b * 32, r1 = min(K, r0 + 32) - 1;
-                const int k0 = row_type(r0), k1 = row_type(r1);
-                if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), b);
-                else if (k0 == 0) emit_rows(std::integral_constant<int, 0>(), b);
-                else if (k0 == 1) emit_rows(std::integral_constant<int, 1>(), b);
-                else if (k0 == 2) emit_rows(std::integral_constant<int, 2>(), b);
-                else emit_rows(std::integral_constant<int, 3>(), b);
-                take_tile(acc[NBW - 1], b);
-            }
-        }
-        if (K4_DBG(1024)) {   // ablation (with dbg & 1): skip the generation but keep non-trivial operand data
-#pragma unroll
-            for (int t = 0; t < NBW; ++t)
-                if (wave + W * t < nb) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        unsigned hsh = (unsigned)(lane * 2654435761u) ^ (unsigned)(((wave + W * t) * 16 + r) * 40503u + blockIdx.x * 97u);
-                        hsh ^= hsh >> 13; hsh *= 0x5bd1e995u; hsh ^= hsh >> 15;
-                        acc[t][r] = (float)(int)(hsh & 0xffff) * (1.0f / 65536.0f) - 0.5f;
-                    }
+        for (int j = 0; j < 4; ++j) {
+            const int q = 8 * qs + 4 * qh + j;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < K && q < jcnt) {
+                const float4 xq = s_xq[q];
+                float d[3] = {xp.x - xq.x, xp.y - xq.y, xp.z - xq.z};
+                float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
+                double e = TABLE ? etab[p * ES + q] : exp((double)(-a * rr));
+                float v0, v1, v2, v3;
+                if (cr == 0) {
+                    v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
+                } else {
+                    const float dr = cr == 1 ? d[0] : (cr == 2 ? d[1] : d[2]);
+                    v0 = -d_kf1(dr, a, e);
+                    // mixed second derivatives: lower component first (covFnc.cpp:300-308)
+                    v1 = (cr == 1) ? d_kf2(rr, d[0], d[0], 1.0f, a, e) : d_kf2(rr, d[0], dr, 0.0f, a, e);
+                    v2 = (cr == 2) ? d_kf2(rr, d[1], d[1], 1.0f, a, e)
+                                   : (cr == 1 ? d_kf2(rr, d[0], d[1], 0.0f, a, e) : d_kf2(rr, d[1], d[2], 0.0f, a, e));
+                    v3 = (cr == 3) ? d_kf2(rr, d[2], d[2], 1.0f, a, e) : d_kf2(rr, dr, d[2], 0.0f, a, e);
                 }
+                if (dim == 2) v3 = 0.f;
+                o = make_float4(v0, v1, v2, v3);
+            }
+            trow[j] = o;
         }
-    }
+    };
+    auto gen_tile = [&](int c, int qs, float* tbuf) {
+        const int r0 = c * 32, r1 = min(K, r0 + 32) - 1;
+        const int k0 = row_type(r0), k1 = row_type(r1);
+        if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), c, qs, tbuf);
+        else if (k0 == 0) emit_rows(std::integral_constant<int, 0>(), c, qs, tbuf);
+        else if (k0 == 1) emit_rows(std::integral_constant<int, 1>(), c, qs, tbuf);
+        else if (k0 == 2) emit_rows(std::integral_constant<int, 2>(), c, qs, tbuf);
+        else emit_rows(std::integral_constant<int, 3>(), c, qs, tbuf);
+    };
 
-    TRACE();
-    // ---- stage 3: blocked forward substitution ----
-    __syncthreads();  // staging strips alias the rings
-    // Dataflow synchronisation instead of a barrier per step: `pub` = last published block,
-    // done[w] = last step whose updates wave w finished.  The owner of block c+1 updates that
-    // tile first, turns it into V_{c+1} and publishes it while the other waves are still busy with
-    // step c.  The owner chain (update -> V = inv(L_cc) U -> publish) is the critical path of the
-    // workgroup; it is two dependent runs of 16 matrix instructions -- the accumulator tile itself is the
-    // B operand of the second run (Lt's diagonal tiles are stored in the matching k order) -- and
-    // executes at raised wave priority.
-    float ss = 0.f;  // partial sum of squares of V over this lane's rows
-    lds_flag_ptr pub = flags;
-    lds_flag_ptr done = flags + 1;
-    // u = U_c (C/D layout), ai = inv(L_cc) operands; returns with V_c published and its squares summed
-    auto invert_publish = [&](const f32x16& u, const float (&ai)[16], int c) {
-        f32x16 v;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = 0.f;
-        if (!K4_DBG(2)) {
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], u[kk], v, 0, 0, 0);
-        }
-        TRACE_OWN();
-        // ring slot free once every wave has finished step c - RING
-        if (c >= RING) {   // one LDS round trip: lane w looks at done[w]
-            while (__builtin_amdgcn_ballot_w64(lane < W && done[lane < W ? lane : 0] < c - RING)) __builtin_amdgcn_s_sleep(1);
-        }
-        // one lane pointer + compile-time row offsets; padding rows >= K hold exact zeros (ongpis_train.hip),
-        // so the sum of squares needs no row predicate
-        float* Vw = Vbuf + (c % RING) * 1024 + (4 * h * 32 + l31);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            Vw[((r & 3) + 8 * (r >> 2)) * 32] = v[r];
-            ss = fmaf(v[r], v[r], ss);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS only: global loads in flight need not drain
-        if (lane == 0) *pub = c;
-        TRACE_OWN();   // published
+    // ---- dataflow between the wavefronts (no barrier in the main loop).  The B chunks of all row groups form one
+    // sequence gci = 0, 1, ...; chunk gci lives in ring slot gci % NSLOT; tile j of a chunk is made by wave j % W.
+    // rdyw[w] = last chunk whose tiles wave w has finished writing, donew[w] = last chunk wave w has finished reading.
+    auto wait_all_ge = [&](lds_flag_ptr f, int v) {
+        if (K4_SYNC_BARRIER) return;
+        while (__builtin_amdgcn_ballot_w64(lane < W && f[lane < W ? lane : 0] < v)) __builtin_amdgcn_s_sleep(1);
     };
-    // av = -L tile operands (Lt holds the negated factor), vb = V_c in MFMA B-operand order
-    auto update_tile = [&](f32x16& a_, const float (&vb)[16], const float (&av)[16]) {
-        if (K4_DBG(4)) return;
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk)
-            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], vb[kk], a_, 0, 0, 0);
+    const int ngroups = (nbx + RG - 1) / RG;
+    auto group_cmax = [&](int g) { return min(nbx - 1 - g * RG, nb - 1); };   // last column block a row of group g multiplies with
+    int pg = 0, pci = 0, pgci = 0;   // producer cursor: group, chunk in group, chunk in sequence
+    auto produce_next = [&]() {
+        if (pg >= ngroups) return;
+        const int cmax = group_cmax(pg);
+        wait_all_ge(donew, pgci - NSLOT);     // every wave has finished reading the chunk that used this slot
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        float* slot = Bbuf + (size_t)(pgci % NSLOT) * CB * QS * kTileFloats;
+        const int c0 = pci * CB;
+        for (int j = wave; j < CB && c0 + j <= cmax; j += W)
+            for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + j, qs, slot + (size_t)(j * QS + qs) * kTileFloats);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+        if (lane == 0) rdyw[wave] = pgci;
+        ++pgci;
+        if (++pci > cmax / CB) { pci = 0; ++pg; }
     };
-    // same, V_c streamed from its LDS ring slot one MFMA pair ahead
-    auto update_tile_lds = [&](f32x16& a_, const float* Vl, const float (&av)[16]) {
-        if (K4_DBG(4)) return;
-        float p0 = Vl[0], p1 = Vl[64];
-#pragma unroll
-        for (int kk = 0; kk < 16; kk += 2) {
-            float n0 = 0.f, n1 = 0.f;
-            if (kk + 2 < 16) { n0 = Vl[(kk + 2) * 64]; n1 = Vl[(kk + 3) * 64]; }
-            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], p0, a_, 0, 0, 0);
-            a_ = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk + 1], p1, a_, 0, 0, 0);
-            p0 = n0; p1 = n1;
-        }
-    };
+
     auto load_a = [&](float (&av)[16], int b, int c) {
         const int sbase = (b * (b + 1) / 2 + c) * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + g * 1024, 0);
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(Xrs, Tvoff, sbase + g * 1024, 0);
             av[4 * g + 0] = __uint_as_float(q[0]); av[4 * g + 1] = __uint_as_float(q[1]);
             av[4 * g + 2] = __uint_as_float(q[2]); av[4 * g + 3] = __uint_as_float(q[3]);
         }
     };
+    // acc_q += X(b, c) B^q_c for the query sets q ; B operand kk of lane (h, n) = B^q_c[2 kk + h][n] from LDS, the
+    // independent accumulator chains of the sets interleaved
+    const bool two = (QS == 2) && (nset == 2);
+    auto mfma_tile = [&](f32x16& acc0, f32x16& acc1, const float (&av)[16], const float* Bt) {
+        const float* Bl = Bt + h * kTileStride + l31;
+        if (K4X & 32) {   // ablation: B operands from registers
+            const float bq = Bl[0];
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq, acc0, 0, 0, 0);
+                if (QS == 2) { if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq + 1.f, acc1, 0, 0, 0); }
+            }
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], Bl[kk * 2 * kTileStride], acc0, 0, 0, 0);
+            if (QS == 2) { if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], Bl[kTileFloats + kk * 2 * kTileStride], acc1, 0, 0, 0); }
+        }
+    };
 
-    if (wave == 0) {  // block 0 has no dependency
-        float ai[16];
-        load_a(ai, 0, 0);
-        invert_publish(acc[0], ai, 0);
-    }
-    // Steps c = tc*W + wc.  Block c+1 belongs to wave (wc+1) mod W; its tile index is tc (same
-    // group) or tc+1 (wave 0 at the group boundary): static after unrolling tc, so the solve
-    // works in place on the accumulator registers.
-#pragma clang loop unroll(full)
-    for (int tc = 0; tc < NBW; ++tc) {
-#pragma unroll 1
-        for (int wc = 0; wc < W; ++wc) {
-            const int c = tc * W + wc;
-            if (c >= nb) break;
-            const bool has_next = (c + 1 < nb);
-            const bool own_same = has_next && (wc + 1 < W) && (wave == wc + 1);
-            const bool own_next = has_next && (wc + 1 == W) && (wave == 0) && (tc + 1 < NBW);
-            const bool owner = own_same || own_next;
-            auto active = [&](int t_) { const int b_ = wave + W * t_; return b_ > c && b_ < nb && b_ != c + 1; };
-            float avp[2][16];   // A operands: [0] doubles as the buffer of the look-ahead tile
-            float vb[VREG ? 16 : 1];
-            // issue the loads this step needs before waiting for V_c
-            if (owner) { load_a(avp[0], c + 1, c); load_a(avp[1], c + 1, c + 1); }   // [1]: inv(L_{c+1,c+1})
-            else if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
-            TRACE();
-            while (*pub < c) __builtin_amdgcn_s_sleep(1);
-            TRACE();
+    float ss[2] = {0.f, 0.f};         // partial sums of squares of V over this lane's rows (order O3, oracle reduce_ss)
+    float mean_val[2] = {0.f, 0.f};   // row K of V (the lane that owns it)
+    const int LA = NSLOT - 1;         // chunks produced ahead of consumption
+    const bool gen_first = (W < 2) || (wave < W / 2);   // half of the waves generate before multiplying, half after
+    for (int i = 0; i < LA; ++i) produce_next();
+    if (K4_SYNC_BARRIER) __syncthreads();
+    K4_STAMP();
+    int gci = 0;
+    for (int g = 0; g < ngroups; ++g) {
+        // this wave's block rows in group g: slot t holds the (g RG + t W + q)-th largest row, q snaking with t
+        int brow[NBW];
+#pragma unroll
+        for (int t = 0; t < NBW; ++t) {
+            const int i = g * RG + t * W + ((t & 1) ? (W - 1 - wave) : wave);
+            brow[t] = nbx - 1 - i;      // < 0: no row
+        }
+        const int cmax = group_cmax(g);
+        const int nch = cmax / CB + 1;
+        f32x16 acc[NBW][QS];
+#pragma unroll
+        for (int t = 0; t < NBW; ++t)
+#pragma unroll
+            for (int q = 0; q < QS; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
+
+        for (int ci = 0; ci < nch; ++ci, ++gci) {
+            if (gen_first && !(K4X & 1)) produce_next();
+            wait_all_ge(rdyw, gci);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            const float* Vb = Vbuf + (c % RING) * 1024 + (h * 32 + l31);   // B operand kk: Vb[64 kk]
-            if (owner) {
-                __builtin_amdgcn_s_setprio(3);
-                auto own_tile = [&](f32x16& a_) {
-                    if constexpr (TR) { TRACE_OWN(); __builtin_amdgcn_s_waitcnt(0x0f70); TRACE_OWN(); }   // vmcnt(0): A operands arrived
-                    if constexpr (VREG) {
-                        float vbo[16];
+            {
+                const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
+                const int c0 = ci * CB;
 #pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) vbo[kk] = Vb[64 * kk];
-                        update_tile(a_, vbo, avp[0]);
-                    } else {
-                        update_tile_lds(a_, Vb, avp[0]);
+                for (int t = 0; t < NBW; ++t) {
+                    const int b = brow[t];
+                    if (b >= c0) {
+                        const int cend = min(min(c0 + CB - 1, b), cmax);
+                        float av[2][16];
+                        load_a(av[0], b, c0);
+#pragma unroll 1
+                        for (int c = c0; c <= cend; c += 2) {
+                            if (c + 1 <= cend && !(K4X & 16)) load_a(av[1], b, c + 1);
+                            mfma_tile(acc[t][0], acc[t][QS - 1], av[0], buf + (size_t)(c - c0) * QS * kTileFloats);
+                            if (c + 1 <= cend) {
+                                if (c + 2 <= cend && !(K4X & 16)) load_a(av[0], b, c + 2);
+                                mfma_tile(acc[t][0], acc[t][QS - 1], av[(K4X & 16) ? 0 : 1], buf + (size_t)(c + 1 - c0) * QS * kTileFloats);
+                            }
+                        }
                     }
-                    TRACE_OWN();
-                    invert_publish(a_, avp[1], c + 1);
-                };
-                if (own_same) own_tile(acc[tc]);
-                if (tc + 1 < NBW) {
-                    if (own_next) own_tile(acc[tc + 1 < NBW ? tc + 1 : tc]);
                 }
-                __builtin_amdgcn_s_setprio(0);
-                if (active(tc)) load_a(avp[tc & 1], wave + W * tc, c);
             }
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (VREG) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            if (lane == 0) donew[wave] = gci;
+            if (!gen_first && !(K4X & 1)) produce_next();
+            if (K4_SYNC_BARRIER) __syncthreads();   // chunk gci consumed and chunk gci + LA produced by every wave
+        }
+        // sums of squares of the finished rows; row K (block nbx-1: group 0, slot 0, wave 0) is the mean
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) vb[kk] = Vb[64 * kk];
-            }
-            TRACE();
-            __builtin_amdgcn_sched_barrier(0);
-            // remaining tiles of this wave (t >= tc), A operands prefetched one tile ahead
+        for (int t = 0; t < NBW; ++t) {
+            if (brow[t] < 0) continue;
+            const bool has_mean = (g == 0 && t == 0 && wave == 0);
+            const int kr = K & 31;
 #pragma unroll
-            for (int t = tc; t < NBW; ++t) {
-                if (t + 1 < NBW) { if (active(t + 1)) load_a(avp[(t + 1) & 1], wave + W * (t + 1), c); }
-                if (active(t)) {
-                    if constexpr (VREG) update_tile(acc[t], vb, avp[t & 1]);
-                    else update_tile_lds(acc[t], Vb, avp[t & 1]);
+            for (int q = 0; q < QS; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[t][q][r];
+                    if (has_mean && rowmap_t(r, h) == kr) mean_val[q] = v;
+                    else ss[q] = fmaf(v, v, ss[q]);
                 }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            TRACE();
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");   // LDS only: global loads in flight need not drain
-            if (lane == 0) done[wave] = c;
         }
     }
-    __syncthreads();
 
-    TRACE();
-    if constexpr (TR) { if (trc && lane == 0) { trc[511] = tri; trc[8 * 512 + 511] = tro; } }
-    // ---- stage 4: reduce partials (lane halves, then waves in fixed order) ----
-    mp = mp + __shfl_xor(mp, 32);
-    ss = ss + __shfl_xor(ss, 32);
-    if (h == 0) { red[(wave * 32 + l31) * 2] = mp; red[(wave * 32 + l31) * 2 + 1] = ss; }
-    __syncthreads();
-    if (wave == 0 && h == 0 && qact) {
-        float ms = 0.f, vs = 0.f;
-        for (int w = 0; w < W; ++w) { ms += red[(w * 32 + l31) * 2]; vs += red[(w * 32 + l31) * 2 + 1]; }
-        float* o = A.out + (size_t)A.job_out[joff + qi] * 8;
-        const float tos = (float)(3.0 / (double)(m.scale * m.scale));  // OnGPIS.h:58
-        float var;
-        if (dim == 3)  // OnGPIS.cpp:208-213
-            var = (cq == 0) ? (float)(1.001 - (double)vs) : (float)((double)tos + 0.001 - (double)vs);
-        else           // OnGPIS.cpp:235-237
-            var = (cq == 0) ? (float)(1.01 - (double)vs) : (float)((double)tos + 0.1 - (double)vs);
-        o[cq] = ms;
-        o[4 + cq] = var;
+    K4_STAMP();
+    // ---- reduce partials (lane halves, then waves in fixed order) ----
+#pragma unroll
+    for (int q = 0; q < QS; ++q) {
+        ss[q] = ss[q] + __shfl_xor(ss[q], 32);
+        if (h == 0) red[wave * NC + q * 32 + l31] = ss[q];
+        if (wave == 0 && h == ((K >> 2) & 1)) red[W * NC + q * 32 + l31] = mean_val[q];   // the half that owns row K & 31
     }
+    __syncthreads();
+    {
+        const int col = tid & 63;                       // wave 0: one lane per (query, component) column
+        const int qi = col >> 2, cq = col & 3;
+        if (wave == 0 && col < NC && qi < jcnt && cq <= dim) {
+            float vs = 0.f;
+            for (int w = 0; w < W; ++w) vs += red[w * NC + col];
+            const float ms = red[W * NC + col];
+            float* o = A.out + (size_t)A.job_out[joff + qi] * 8;
+            const float tos = (float)(3.0 / (double)(scale * scale));  // OnGPIS.h:58
+            float var;
+            if (dim == 3)  // OnGPIS.cpp:208-213
+                var = (cq == 0) ? (float)(1.001 - (double)vs) : (float)((double)tos + 0.001 - (double)vs);
+            else           // OnGPIS.cpp:235-237
+                var = (cq == 0) ? (float)(1.01 - (double)vs) : (float)((double)tos + 0.1 - (double)vs);
+            o[cq] = ms;
+            o[4 + cq] = var;
+        }
+    }
+    K4_STAMP();
+#undef K4_STAMP
 }
 
-// Size classes by nb = ceil(K/32): W waves x NBW tiles per wave (ongpis.h, ongpis_class_of_nb).
-static const int kClassW[6] = {1, 2, 4, 8, 16, 8};
-static const int kClassNb[6] = {4, 8, 16, 32, 64, 96};
+// Size classes by nbx = ceil((K+1)/32): W wavefronts per workgroup (ongpis.h, ongpis_class_of_nbx).
+#ifndef K4_W3
+#define K4_W3 8            // wavefronts per workgroup of the widest class
+#endif
+#ifndef K4_NBW
+#define K4_NBW 4
+#endif
+static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, K4_W3};
+constexpr int kQS = ONGPIS_TILE_Q / 8;
+constexpr int kWavesPerCU = 4 * K4_MINW;   // resident wavefronts per CU the register budget of the kernels admits
 
-static size_t eval_lds_bytes(int W, int maxN, int maxLd, int use_table) {
-    size_t fixed = sizeof(float) * (W * 128 + 32) + sizeof(float) * 2 * (size_t)maxLd + 16 * (size_t)maxN;
-    size_t s2 = sizeof(float) * (size_t)W * 1152 + (use_table ? sizeof(double) * 8 * (size_t)maxN : 0);
-    size_t s3 = sizeof(float) * 4 * 1024;   // RING = 4 published V blocks
-    return fixed + std::max(s2, s3);
+static size_t eval_lds_fixed(int W, int maxN, int maxLd, int use_table) {
+    return sizeof(float) * (W * 32 * kQS + 32 * kQS) + 16 * sizeof(float4) + 32 * sizeof(int) + sizeof(int) * (size_t)maxLd + 16 * (size_t)maxN +
+           (use_table ? sizeof(double) * (((size_t)maxN * (8 * kQS + 1) + 1) & ~(size_t)1) : 0);
 }
 
-int ongpis_eval_launch(int wclass, int ntiles, int maxN, const EvalArgs& args_in, hipStream_t s) {
+int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args_in, hipStream_t s) {
     if (ntiles <= 0) return GPIS_OK;
     if (wclass < 0 || wclass >= ONGPIS_NCLASS) return GPIS_ERR_ARG;
     EvalArgs args = args_in;
     const int W = kClassW[wclass];
-    const int maxLd = kClassNb[wclass] * 32 + 32;
-    const size_t budget = 150 * 1024;     // one workgroup must fit; two per CU when <= 80 KB
-    args.use_table = 1; args.lds_model = 1;
-    args.dbg = 0; args.trace = nullptr; args.trace_block = 0;
-#ifdef GPIS_K4_INSTRUMENT
-    { const char* e = getenv("GPIS_K4_DBG"); args.dbg = e ? atoi(e) : 0; }
-    static unsigned long long* d_trace = nullptr;
-    if (const char* e = getenv("GPIS_K4_TRACE")) {
-        if (!d_trace) { (void)hipMalloc(&d_trace, sizeof(unsigned long long) * 512 * 16); }
-        (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 512 * 16, s);
-        args.trace = d_trace; args.trace_block = atoi(e);
+    // LDS budget: the register file admits kWavesPerCU wavefronts per CU, i.e. kWavesPerCU / W workgroups; give each an
+    // equal share of the 160 KB and spend what the per-cluster tables leave on the ring of B chunks: NSLOT slots
+    // of cb column blocks x kQS query sets (three slots of >= 2 blocks when they fit, else two; cb <= 8).
+    const size_t hard = 158 * 1024;
+    const size_t share = std::min(hard, hard * W / kWavesPerCU);
+    const size_t blk = kQS * sizeof(float) * kTileFloats;    // one column block, all query sets
+    int use_table = args_in.use_table ? 1 : 0;
+    size_t fixed = eval_lds_fixed(W, maxN, maxLd, use_table);
+    if (use_table && fixed + 4 * blk > share) {              // the exp table does not fit beside a useful ring
+        const size_t f0 = eval_lds_fixed(W, maxN, maxLd, 0);
+        if (f0 + 4 * blk <= share || fixed + 2 * blk > hard) { use_table = 0; fixed = f0; }
     }
+    if (fixed + 2 * blk > hard) return GPIS_ERR_LIMIT;
+    const size_t budget = std::min(hard, std::max(share, fixed + 2 * blk));
+    const int nblk = (int)((budget - fixed) / blk);           // column blocks the ring can hold
+#ifdef K4_NSLOT
+    int nslot = K4_NSLOT;
+#else
+    int nslot = 2;   // two large chunks beat three smaller ones (fewer synchronisation points): 811 vs 851 ms on the 256^3 bench
 #endif
-    size_t lds = eval_lds_bytes(W, maxN, maxLd, 1);
-    if (lds > budget) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }
-    if (lds > budget) return GPIS_ERR_LIMIT;
-    if (args.use_table && args_in.use_table == 0) { args.use_table = 0; lds = eval_lds_bytes(W, maxN, maxLd, 0); }   // caller asked for the table-free path (large-cluster path; tests force it)
+    int cb = std::max(1, std::min(nblk / nslot, 8));
+    cb = std::min(cb, std::max(1, maxLd / 32));
+    args.use_table = use_table;
+    args.cb = cb;
+    args.nslot = nslot;
+    const size_t lds = fixed + (size_t)nslot * cb * blk;
     typedef void (*kern_t)(EvalArgs);
-    static const kern_t kern[ONGPIS_NCLASS] = {
-        ongpis_eval_kernel<1, 4, 2, true, false>, ongpis_eval_kernel<2, 4, 2, true, false>,
-        ongpis_eval_kernel<4, 4, 2, true, false>, ongpis_eval_kernel<8, 4, 4, false, false>,
-        ongpis_eval_kernel<16, 4, 4, false, false>, ongpis_eval_kernel<8, 12, 2, true, false>};
+    static const kern_t kern[2][ONGPIS_NCLASS] = {
+        {ongpis_eval_kernel<1, false, kQS, K4_NBW>, ongpis_eval_kernel<2, false, kQS, K4_NBW>, ongpis_eval_kernel<4, false, kQS, K4_NBW>,
+         ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW>},
+        {ongpis_eval_kernel<1, true, kQS, K4_NBW>, ongpis_eval_kernel<2, true, kQS, K4_NBW>, ongpis_eval_kernel<4, true, kQS, K4_NBW>,
+         ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW>}};
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
-        for (int i = 0; i < ONGPIS_NCLASS; ++i)
-            (void)hipFuncSetAttribute((const void*)kern[i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        for (int t = 0; t < 2; ++t)
+            for (int i = 0; i < ONGPIS_NCLASS; ++i)
+                (void)hipFuncSetAttribute((const void*)kern[t][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-#ifdef GPIS_K4_INSTRUMENT
-    static const kern_t kern_tr = ongpis_eval_kernel<8, 4, 4, false, true>;   // traced build of class 3
-    if (args.trace && wclass == 3) {
-        (void)hipFuncSetAttribute((const void*)kern_tr, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(kern_tr, dim3(ntiles), dim3(64 * W), lds, s, args);
+#if K4X & 64
+    static unsigned long long* d_trace = nullptr;
+    if (!d_trace) { (void)hipMalloc(&d_trace, sizeof(unsigned long long) * 64 * 64); }
+    (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 64 * 64, s);
+    args.trace = d_trace;
+#endif
+    hipLaunchKernelGGL(kern[use_table][wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
+#if K4X & 64
+    {
         (void)hipStreamSynchronize(s);
-        static unsigned long long h[512 * 16];
-        (void)hipMemcpy(h, d_trace, sizeof(h), hipMemcpyDeviceToHost);
+        static unsigned long long hb[64 * 64];
+        (void)hipMemcpy(hb, d_trace, sizeof(hb), hipMemcpyDeviceToHost);
         FILE* f = fopen("gpurun_out/k4_trace.txt", "w");
         if (f) {
-            for (int w = 0; w < 2 * W; ++w) {   // rows W..2W-1: owner-path events
-                int n = (int)h[w * 512 + 511];
-                fprintf(f, "wave %d n %d\n", w, n);
-                for (int i = 0; i < n && i < 511; ++i) fprintf(f, "%llu\n", h[w * 512 + i] - h[0]);
+            for (int g = 0; g < 64; ++g) {
+                if (!hb[g * 64]) continue;
+                for (int w = 0; w < 8; ++w) {
+                    fprintf(f, "wg %d wave %d:", g, w);
+                    for (int i = 0; i < 8; ++i) if (hb[g * 64 + w * 8 + i]) fprintf(f, " %llu", hb[g * 64 + w * 8 + i] - hb[g * 64]);
+                    fprintf(f, "\n");
+                }
             }
             fclose(f);
         }
-        return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
     }
 #endif
-    hipLaunchKernelGGL(kern[wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
     return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
 }
 
-int ongpis_eval_class(int nb) {
-    for (int c = 0; c < ONGPIS_NCLASS; ++c) if (nb <= kClassNb[c]) return c;
-    return -1;
-}
+int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }
 
 }  // namespace gpis

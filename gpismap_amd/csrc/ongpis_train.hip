@@ -18,6 +18,8 @@
 
 namespace gpis {
 
+typedef const float __attribute__((address_space(1))) * gfptr_t;
+
 #define JOB_MODEL(j) d_jobs[4 * (j) + 0]
 #define JOB_OFF(j) d_jobs[4 * (j) + 1]
 #define JOB_N(j) d_jobs[4 * (j) + 2]
@@ -412,6 +414,114 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// K3b: explicit inverse X = L^-1 of a trained factor, re-tiled for K4.  grid = (job, block column) pairs,
+// block = ONE wavefront: block column c of X is independent of every other column,
+//     X_cc = inv(L_cc),     X_bc = inv(L_bb) * sum_{p=c}^{b-1} (-L_bp) X_pc      (b > c)
+// i.e. the blocked forward substitution of the oracle (linalg.hpp fwd_subst_blocked) applied to the 32 unit
+// vectors of block c: the sum is a chain of v_mfma_f32_32x32x2_f32 over ascending p and k starting from zero
+// (A operand = the re-tiled -L from Lt, B operand = the transposed tile (X_pc)^T from Zt, which read in A-operand
+// order IS X_pc in B-operand order), the product with inv(L_bb) is a second run of 16 matrix instructions whose B
+// operand is the accumulator tile itself (Lt's diagonal tiles hold the inverse in the matching k order, (O6)).
+// Each finished tile goes through a padded LDS tile once and is written twice, 16 bytes per lane: as Xt(b, c) for
+// K4 and as Zt(b, c) = (X_bc)^T for this wave's own later rows.  Row K of X is replaced by alpha (K4 reads the mean
+// off row K of V = X k*).  A cluster of nb block rows is nb independent wavefronts; a batch of clusters fills the chip.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
+                                                         const int* __restrict__ d_jobs, const int* __restrict__ work) {
+    __shared__ __attribute__((aligned(16))) float T[32 * 36];
+    const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    const int job = work[2 * blockIdx.x], c = work[2 * blockIdx.x + 1];
+    const ClusterModel m = models[JOB_MODEL(job)];
+    const int K = m.K, nb = m.nb, nbx = m.ld / 32;
+    const int ntl = nbx * (nbx + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const int Tvoff = lane * 16;
+    auto load_tile = [&](float (&o)[16], const __amdgpu_buffer_rsrc_t& rs, int b, int cc) {
+        const int sbase = tri_index(b, cc) * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(rs, Tvoff, sbase + g * 1024, 0);
+            o[4 * g + 0] = __uint_as_float(q[0]); o[4 * g + 1] = __uint_as_float(q[1]);
+            o[4 * g + 2] = __uint_as_float(q[2]); o[4 * g + 3] = __uint_as_float(q[3]);
+        }
+    };
+    // x = X_bc in C/D layout (lane = column, 16 rows per lane half) -> Xt(b, c) and Zt(b, c)
+    gfptr_t g_alpha = (gfptr_t)m.alpha;
+    auto emit = [&](const f32x16& x, int b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[rowmap_t(r, h) * 36 + l31] = x[r];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float4* xt = reinterpret_cast<float4*>(m.Xt + (size_t)tri_index(b, c) * 1024);
+        float4* zt = reinterpret_cast<float4*>(m.Zt + (size_t)tri_index(b, c) * 1024);
+        const bool mean_row = (32 * b + l31 == K);   // this lane's row of X_bc is row K: alpha instead
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 q, z;
+            float* qa = reinterpret_cast<float*>(&q);
+            float* za = reinterpret_cast<float*>(&z);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = 2 * (4 * g + j) + h;
+                float v = T[l31 * 36 + k];                     // X_bc[l31][k]
+                if (mean_row) { const int col = 32 * c + k; v = (col < K) ? g_alpha[col] : 0.f; }
+                qa[j] = v;
+                za[j] = T[k * 36 + l31];                       // (X_bc)^T[l31][k]
+            }
+            xt[g * 64 + lane] = q;
+            zt[g * 64 + lane] = z;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto times_inverse = [&](const f32x16& sacc, int b) {   // inv(L_bb) * S, S = accumulator tile as the B operand
+        float ai[16];
+        load_tile(ai, Lrs, b, b);
+        f32x16 v;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], sacc[kk], v, 0, 0, 0);
+        return v;
+    };
+    {   // diagonal tile: inv(L_cc) times the identity
+        f32x16 e;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) e[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
+        emit(times_inverse(e, c), c);
+    }
+    for (int b = c + 1; b < nb; ++b) {
+        __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): this wave's Zt stores are complete before it reads them back
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        float av[2][16], zb[2][16];
+        load_tile(av[0], Lrs, b, c);
+        load_tile(zb[0], Zrs, c, c);
+#pragma unroll 1
+        for (int p = c; p < b; p += 2) {
+            if (p + 1 < b) { load_tile(av[1], Lrs, b, p + 1); load_tile(zb[1], Zrs, p + 1, c); }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk], zb[0][kk], sacc, 0, 0, 0);
+            if (p + 1 < b) {
+                if (p + 2 < b) { load_tile(av[0], Lrs, b, p + 2); load_tile(zb[0], Zrs, p + 2, c); }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk], zb[1][kk], sacc, 0, 0, 0);
+            }
+        }
+        emit(times_inverse(sacc, b), b);
+    }
+    // K a multiple of 32: row K sits alone in an extra block row (nb = nbx - 1) whose tiles hold only alpha
+    if (nbx > nb) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        emit(z, nb);
+    }
+}
+
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_gather_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs, d_ids, d_pts, pts_cap);
@@ -424,6 +534,10 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
     if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<3, 1>), dim3(njobs), dim3(64), 0, s, d_models, d_jobs);
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
+}
+
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nwork, hipStream_t s) {
+    if (nwork > 0) hipLaunchKernelGGL(ongpis_inv_kernel, dim3(nwork), dim3(64), 0, s, d_models, d_jobs, d_work);
 }
 
 }  // namespace gpis

@@ -68,10 +68,10 @@ struct GPou {
                 else v = ou_k(dist_n(&x[(size_t)dim * k], &x[(size_t)dim * j], dim), a);
                 L[j + (size_t)k * n] = v;  // lower triangle only
             }
-        chol_lower(L.data(), n, n);
+        chol_lower_m(L.data(), n, n);
         alpha.assign(f, f + n);
-        fwd_subst(L.data(), n, n, alpha.data(), 1, n);
-        bwd_subst(L.data(), n, n, alpha.data());
+        fwd_subst_m(L.data(), n, n, alpha.data(), 1, n);
+        bwd_subst_m(L.data(), n, n, alpha.data());
         trained = true;
     }
 
@@ -86,6 +86,14 @@ struct GPou {
         for (int i = 0; i < n; ++i) {
             ks[i] = ou_k(dist_n(&x[(size_t)dim * i], xt, dim), a);
             p[i] = ks[i] * alpha[i];
+        }
+        if (arith_mode() != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
+            const bool d64 = arith_mode() == ARITH_FP64ACC;
+            f = d64 ? dot_nat<double>(ks, alpha.data(), n) : dot_nat<float>(ks, alpha.data(), n);
+            fwd_subst_m(L.data(), n, n, ks, 1, 64);
+            const float ss = d64 ? dot_nat<double>(ks, ks, n) : dot_nat<float>(ks, ks, n);
+            var = d64 ? (float)((double)(1 + noise) - (double)ss) : (1 + noise) - ss;
+            return;
         }
         for (int off = 32; off >= 1; off >>= 1) {
             float q[64];
@@ -382,6 +390,7 @@ struct OnGPIS {
     std::vector<int> gidx;
     std::vector<float> L, alpha;
     std::vector<float> Linv;   // inverted 32x32 diagonal blocks of L (linalg.hpp, fwd_subst_blocked)
+    std::vector<float> X;      // tiled mode: explicit inverse X = L^-1, ROW-major K x K (lower), see train()
 
     OnGPIS(int dim_, float s) : dim(dim_), scale(s), three_over_scale((float)(3.0 / (double)(s * s))) {}
 
@@ -409,32 +418,53 @@ struct OnGPIS {
         }
         L.assign((size_t)K * K, 0.f);
         matern32_train_lower(dim, N, x.data(), gidx.data(), ng, scale, sigx.data(), sigg.data(), L.data(), K);
-        chol_lower(L.data(), K, K);
+        chol_lower_m(L.data(), K, K);
         alpha = y;
-        fwd_subst(L.data(), K, K, alpha.data(), 1, K);
-        bwd_subst(L.data(), K, K, alpha.data());
-        blocked_diag_inverses(L.data(), K, K, Linv);
+        fwd_subst_m(L.data(), K, K, alpha.data(), 1, K);
+        bwd_subst_m(L.data(), K, K, alpha.data());
+        if (arith_mode() == ARITH_TILED) {
+            // Explicit inverse of the factor (tiled mode).  A prediction needs V = L^-1 k*; with X = L^-1 formed once
+            // per training this is a triangular matrix product without any dependency between its rows -- the form
+            // the batched GPU predictor runs on the matrix cores.  X is computed by the blocked forward substitution
+            // of linalg.hpp on the columns of the identity (32 x 32 diagonal blocks through their inverses, orders
+            // (O1)/(O6)); a column starts at its own block, the rows above are exact zeros.  Accuracy against an fp64
+            // solve with the same factor: DESIGN.md section 2 (var_f error <= 5e-6 on trained cluster factors).
+            blocked_diag_inverses(L.data(), K, K, Linv);
+            X.assign((size_t)K * K, 0.f);
+            std::vector<float> e(K);
+            for (int j = 0; j < K; ++j) {
+                const int r0 = (j / 32) * 32;
+                std::fill(e.begin(), e.end(), 0.f);
+                e[j] = 1.f;
+                fwd_subst_blocked(L.data() + r0 + (size_t)r0 * K, Linv.data() + (size_t)(r0 / 32) * 1024, K - r0, K, e.data() + r0, 1, K);
+                for (int i = j; i < K; ++i) X[(size_t)i * K + j] = e[i];
+            }
+        }
         trained = true;
     }
 
-    // Reduction order (O3) of the two long sums k*^T alpha and sum(v^2).  Eigen evaluates them
-    // with packet-wise interleaved partial sums (order unspecified); this restatement fixes
-    // 2*W interleaved partial chains: row r goes to chain (w, h) with w = (r / 32) mod W,
-    // h = (r / 4) mod 2, each chain is an ascending fmaf chain, the pair (w,0)+(w,1) is added,
-    // and the W pair sums are accumulated in ascending w.  W = 1, 2, 4, 8, 16 for K <= 128, 256, 512,
-    // 1024, 2048 and 8 above.  (This is the order a 32x32-tiled solve over W cooperating wavefronts produces.)
-    static int chains_W(int K) {
-        int nb = (K + 31) / 32;
-        return nb <= 4 ? 1 : (nb <= 8 ? 2 : (nb <= 16 ? 4 : (nb <= 32 ? 8 : (nb <= 64 ? 16 : 8))));
-    }
-    template <class F>
-    static float reduce_O3(int K, F&& term_chain) {
-        const int W = chains_W(K);
-        float P[16][2];
-        for (int w = 0; w < 16; ++w) P[w][0] = P[w][1] = 0.f;
-        for (int r = 0; r < K; ++r) {
-            int w = (r >> 5) % W, h = (r >> 2) & 1;
-            P[w][h] = term_chain(r, P[w][h]);
+    // Reduction order (O3) of the sum of squares ||V||^2 (tiled mode).  Eigen evaluates it with packet-wise
+    // interleaved partial sums (order unspecified); this restatement fixes the order in which a 32x32-tiled
+    // triangular product over W cooperating wavefronts meets the rows.  With nbx = ceil((K+1)/32) block rows
+    // (row K carries the mean, below), W = 1, 2, 4, 8 for nbx <= 4, 8, 16, more.  Block rows are dealt to the
+    // wavefronts from the LARGEST down, in groups of 4W, snake-wise (block row b costs b+1 tile products, the snake
+    // balances the wavefronts): the i-th largest row b = nbx-1-i has group g = i / 4W, slot t = (i % 4W) / W,
+    // position q = i % W and belongs to wavefront w = (t odd) ? W-1-q : q.  Inside a 32-row block the two lane
+    // halves h = 0, 1 own the rows (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  Chain (w, h) takes fmaf(v, v, .) over
+    // its rows in the order (g, t, r) ascending; then (w,0)+(w,1) are added and the W sums accumulated in ascending w.
+    static int chains_W(int nbx) { return nbx <= 4 ? 1 : (nbx <= 8 ? 2 : (nbx <= 16 ? 4 : 8)); }
+    static float reduce_ss(int K, const float* v) {
+        const int nbx = (K + 1 + 31) / 32, W = chains_W(nbx), RG = 4 * W;
+        float P[8][2];
+        for (int w = 0; w < 8; ++w) P[w][0] = P[w][1] = 0.f;
+        for (int i = 0; i < nbx; ++i) {            // i ascending = (g, t) ascending for every wavefront
+            const int b = nbx - 1 - i, ii = i % RG, t = ii / W, q = ii % W;
+            const int w = (t & 1) ? W - 1 - q : q;
+            for (int h = 0; h < 2; ++h)
+                for (int r = 0; r < 16; ++r) {
+                    const int row = 32 * b + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (row < K) P[w][h] = fmaf(v[row], v[row], P[w][h]);
+                }
         }
         float s = 0.f;
         for (int w = 0; w < W; ++w) s += (P[w][0] + P[w][1]);
@@ -447,14 +477,37 @@ struct OnGPIS {
         const int nc = 1 + dim;
         std::vector<float> ks((size_t)K * nc);
         matern32_cross1(dim, N, x.data(), gidx.data(), ng, scale, xq, ks.data(), K);
-        for (int c = 0; c < nc; ++c) {
-            const float* col = &ks[(size_t)c * K];
-            mean[c] = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], alpha[r], acc); });
+        if (arith_mode() != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
+            const bool d64 = arith_mode() == ARITH_FP64ACC;
+            for (int c = 0; c < nc; ++c) {
+                const float* col = &ks[(size_t)c * K];
+                mean[c] = d64 ? dot_nat<double>(col, alpha.data(), K) : dot_nat<float>(col, alpha.data(), K);
+            }
+            fwd_subst_m(L.data(), K, K, ks.data(), nc, K);
+            for (int c = 0; c < nc; ++c) {
+                const float* col = &ks[(size_t)c * K];
+                const float s = d64 ? dot_nat<double>(col, col, K) : dot_nat<float>(col, col, K);
+                if (dim == 3) var[c] = (c == 0) ? (float)(1.001 - (double)s) : (float)((double)three_over_scale + 0.001 - (double)s);
+                else var[c] = (c == 0) ? (float)(1.01 - (double)s) : (float)((double)three_over_scale + 0.1 - (double)s);
+            }
+            return;
         }
-        fwd_subst_blocked(L.data(), Linv.data(), K, K, ks.data(), nc, K);   // matrix rhs: blocked solve (linalg.hpp)
+        // Tiled mode.  Mean: ONE fmaf chain over ascending rows (alpha rides along as row K of the inverse, so the
+        // matrix product delivers k*^T alpha in the natural order).  V = X k*: every element one fmaf chain from zero
+        // over ascending k (terms beyond the diagonal are exact zeros).  Sum of squares: reduce_ss (O3).
+        std::vector<float> v(K);
         for (int c = 0; c < nc; ++c) {
             const float* col = &ks[(size_t)c * K];
-            float s = reduce_O3(K, [&](int r, float acc) { return fmaf(col[r], col[r], acc); });
+            float m = 0.f;
+            for (int r = 0; r < K; ++r) m = fmaf(alpha[r], col[r], m);
+            mean[c] = m;
+            for (int r = 0; r < K; ++r) {
+                const float* xr = &X[(size_t)r * K];
+                float a = 0.f;
+                for (int k = 0; k <= r; ++k) a = fmaf(xr[k], col[k], a);
+                v[r] = a;
+            }
+            const float s = reduce_ss(K, v.data());
             if (dim == 3)  // OnGPIS.cpp:208-213
                 var[c] = (c == 0) ? (float)(1.001 - (double)s)
                                   : (float)((double)three_over_scale + 0.001 - (double)s);

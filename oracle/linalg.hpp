@@ -127,4 +127,96 @@ static inline void bwd_subst(const float* L, int n, int ld, float* b) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Arithmetic variants (SURVEY 8(c) "fp32 and fp64-accumulate variants").  The routines above
+// fix the summation orders a tiled GPU implementation reproduces bit for bit ("tiled", mode 0 -- the default
+// and the only mode the product is compared with bit-exactly).  Eigen's own orders are unknowable without
+// Eigen, so two INDEPENDENT orders of the same textbook operations are provided to show that the results
+// do not depend on the order beyond fp32 round-off:
+//   mode 1 "natural": what a plain non-blocked implementation does -- every element is
+//          (a - (p_1 + p_2 + ... )) / d with the products summed left to right, separate multiply and
+//          add roundings (no fused multiply-add, as an x86 build without -mfma), plain substitution for
+//          the matrix right-hand side of a prediction (no blocks, no explicit inverses), sequential
+//          left-to-right dot products and sums of squares;
+//   mode 2 "fp64acc": the same algorithm as mode 1 with every accumulator (and the final subtract /
+//          divide / sqrt of an element) in double, stored values rounded once to float.
+// The mode is process-global test state (orc_set_arith_mode); it is read, never written, while a map runs.
+// ---------------------------------------------------------------------------------------------------------
+enum { ARITH_TILED = 0, ARITH_NATURAL = 1, ARITH_FP64ACC = 2 };
+inline int& arith_mode() { static int m = ARITH_TILED; return m; }
+
+template <class T>
+static inline void chol_lower_nat(float* A, int n, int ld) {
+    std::vector<T> s(n > 0 ? n : 1);
+    std::vector<float> xs(n > 0 ? n : 1);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < i; ++j) s[j] = (T)0;
+        T d = (T)0;
+        for (int k = 0; k < i; ++k) {
+            const float* col = A + (size_t)k * ld;
+            const float xk = (float)(((T)A[i + (size_t)k * ld] - s[k]) / (T)col[k]);
+            xs[k] = xk;
+            const T xt = (T)xk;
+            for (int j = k + 1; j < i; ++j) s[j] += (T)col[j] * xt;
+            d += xt * xt;
+        }
+        for (int j = 0; j < i; ++j) A[i + (size_t)j * ld] = xs[j];
+        A[i + (size_t)i * ld] = (float)std::sqrt((T)A[i + (size_t)i * ld] - d);
+    }
+}
+template <class T>
+static inline void fwd_subst_nat(const float* L, int n, int ld, float* B, int nrhs, int ldb) {
+    std::vector<T> s(n > 0 ? n : 1);
+    for (int c = 0; c < nrhs; ++c) {
+        float* b = B + (size_t)c * ldb;
+        for (int j = 0; j < n; ++j) s[j] = (T)0;
+        for (int k = 0; k < n; ++k) {
+            const float* col = L + (size_t)k * ld;
+            const float xk = (float)(((T)b[k] - s[k]) / (T)col[k]);
+            b[k] = xk;
+            const T xt = (T)xk;
+            for (int j = k + 1; j < n; ++j) s[j] += (T)col[j] * xt;
+        }
+    }
+}
+template <class T>
+static inline void bwd_subst_nat(const float* L, int n, int ld, float* b) {
+    for (int j = n - 1; j >= 0; --j) {
+        const float* col = L + (size_t)j * ld;
+        T s = (T)0;
+        for (int k = j + 1; k < n; ++k) s += (T)col[k] * (T)b[k];
+        b[j] = (float)(((T)b[j] - s) / (T)col[j]);
+    }
+}
+template <class T>
+static inline float dot_nat(const float* a, const float* b, int n) {
+    T s = (T)0;
+    for (int i = 0; i < n; ++i) s += (T)a[i] * (T)b[i];
+    return (float)s;
+}
+
+// mode-dispatching entry points used by gp.hpp
+static inline void chol_lower_m(float* A, int n, int ld) {
+    switch (arith_mode()) {
+        case ARITH_NATURAL: chol_lower_nat<float>(A, n, ld); break;
+        case ARITH_FP64ACC: chol_lower_nat<double>(A, n, ld); break;
+        default: chol_lower(A, n, ld);
+    }
+}
+static inline void fwd_subst_m(const float* L, int n, int ld, float* B, int nrhs, int ldb) {
+    switch (arith_mode()) {
+        case ARITH_NATURAL: fwd_subst_nat<float>(L, n, ld, B, nrhs, ldb); break;
+        case ARITH_FP64ACC: fwd_subst_nat<double>(L, n, ld, B, nrhs, ldb); break;
+        default: fwd_subst(L, n, ld, B, nrhs, ldb);
+    }
+}
+static inline void bwd_subst_m(const float* L, int n, int ld, float* b) {
+    switch (arith_mode()) {
+        case ARITH_NATURAL: bwd_subst_nat<float>(L, n, ld, b); break;
+        case ARITH_FP64ACC: bwd_subst_nat<double>(L, n, ld, b); break;
+        default: bwd_subst(L, n, ld, b);
+    }
+}
+
 }  // namespace orc

@@ -57,6 +57,7 @@ def lib():
         L.orc2_get_nodes.argtypes = [C.c_void_p, fp, C.c_int]
         L.orc2_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         L.orc2_obsgp_sizes.argtypes = [C.c_void_p, ip, C.c_int]
+        L.orc_set_arith_mode.argtypes = [C.c_int]
         L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
         L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
         L.orc_fwd_subst_blocked.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
@@ -69,6 +70,16 @@ def lib():
         L.orc_ongpis_predict.argtypes = [C.c_int, C.c_float, fp, fp, fp, fp, fp, C.c_int, fp, C.c_int, fp]
         _LIB = L
     return _LIB
+
+
+ARITH_MODES = {"tiled": 0, "natural": 1, "fp64acc": 2}
+
+
+def set_arith_mode(mode):
+    """Arithmetic variant of every subsequent oracle training / prediction (oracle/linalg.hpp): "tiled" (default;
+    the orders the HIP kernels reproduce bit for bit), "natural" (plain left-to-right fp32, no fma, plain
+    substitution) or "fp64acc" (natural order with double accumulators).  Process-global; reset to "tiled" after use."""
+    lib().orc_set_arith_mode(ARITH_MODES[mode] if isinstance(mode, str) else int(mode))
 
 
 def ongpis_train(dim, scale, pos, grad, val, sx, sg):

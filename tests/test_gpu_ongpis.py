@@ -156,11 +156,24 @@ def test_predict_without_exp_table_is_identical():
     assert np.array_equal(with_table.view(np.uint32), without.view(np.uint32))
 
 
-def test_oversize_cluster_is_refused():
+def test_large_cluster_beyond_one_row_group():
+    """K = 3600 (113 block rows): four row groups of K4's widest class, B chunks regenerated per group; the round-1
+    build refused K > 3072 (the reference has no size limit, OnGPIS.cpp:91-149).  Factor, alpha and predictions
+    bit-identical to the oracle."""
     import gpismap_amd
     rng = np.random.default_rng(3)
-    n = 900                                    # K = 3600 > 3072
+    n = 900
     pos, nrm, val, sx, sg = make_cluster(rng, 3, n, 0.04, frac_nograd=0.0)
     st = gpismap_amd.OnGPIS(3, 0.04)
-    with pytest.raises(gpismap_amd.GpisError):
-        st.train(soa9(3, pos, nrm, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    models = st.train(soa9(3, pos, nrm, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    m = st.model(models[0])
+    assert m["K"] == 3600
+    o = oracle_lib.ongpis_train(3, 0.04, pos, nrm, val, sx, sg)
+    assert np.array_equal(np.tril(m["L"][:3600, :3600]).view(np.uint32), np.tril(o["L"]).view(np.uint32))
+    assert np.array_equal(m["alpha"].view(np.uint32), o["alpha"].view(np.uint32))
+    nq = 19
+    xq = (pos[rng.integers(0, n, nq)] + rng.normal(0, 0.012, (nq, 3))).astype(np.float32)
+    ref = oracle_lib.ongpis_predict(3, 0.04, pos, nrm, val, sx, sg, xq)
+    out = st.eval(xq, np.arange(nq, dtype=np.int32), np.full(nq, models[0], dtype=np.int32))
+    got = np.concatenate([out[:, :4], out[:, 4:8]], axis=1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))

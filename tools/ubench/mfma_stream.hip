@@ -5,12 +5,13 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <int WAVES, int MINW, bool GLOAD, bool LDSB>
 __global__ __launch_bounds__(64 * WAVES, MINW) void k(const float* __restrict__ A, float* out, int steps, int ntile_bytes) {
     __shared__ float V[4][1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = 0.001f * (i & 31);
+    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = A[(i * 7 + blockIdx.x * 13) & 1048575] + 0.001f * (i & 31);
     __syncthreads();
     f32x16 acc[4];
     for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void kstep(const float* __restric
     __shared__ float V[4][1024];
     __shared__ volatile int flags[32];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = 0.001f * (i & 31);
+    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = A[(i * 7 + blockIdx.x * 13) & 1048575] + 0.001f * (i & 31);
     if (threadIdx.x < 32) flags[threadIdx.x] = 1 << 30;
     __syncthreads();
     f32x16 acc[4];
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64 * WAVES, MINW) void kstep_dma(const float* __res
     __shared__ __attribute__((aligned(16))) float S[WAVES][2][1024];
     __shared__ volatile int flags[32];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = 0.001f * (i & 31);
+    for (int i = threadIdx.x; i < 4096; i += 64 * WAVES) (&V[0][0])[i] = A[(i * 7 + blockIdx.x * 13) & 1048575] + 0.001f * (i & 31);
     if (threadIdx.x < 32) flags[threadIdx.x] = 1 << 30;
     __syncthreads();
     f32x16 acc[4];
@@ -224,9 +225,25 @@ static void runstep_dma(int wgs_per_cu, const float* dA, float* dout, int steps,
     double flop = (double)grid * WAVES * steps * TILES * 16 * 4096.0;
     printf("stepped + LDS-DMA first tile, %d/step waves/WG %2d WG/CU %d: %.3f ms  %.1f TFLOP/s (%.1f%%)\n", TILES, WAVES, wgs_per_cu, ms, flop / ms / 1e9, 100 * flop / ms / 1e9 / 157.3);
 }
-int main() {
+// argv[1] = "random": A tiles and the LDS operand block hold random normals instead of zeros / small constants.  The gfx950
+// clock follows the power budget and matrix-pipe power follows operand toggling: the zero-data numbers are the
+// scheduling ceiling, the random-data numbers the ceiling a real kernel can reach.
+static bool g_random = false;
+int main(int argc, char** argv) {
     const int bytes = 1024 * 4096;
+    g_random = argc > 1 && argv[1][0] == 'r';
     float *dA, *dout; hipMalloc(&dA, bytes); hipMemset(dA, 0, bytes); hipMalloc(&dout, 4 * 1024 * 1024 * 4);
+    if (g_random) {
+        float* h = (float*)malloc(bytes);
+        srand(7);
+        for (int i = 0; i < bytes / 4; ++i) {
+            float u1 = (rand() + 1.f) / (RAND_MAX + 2.f), u2 = rand() / (float)RAND_MAX;
+            h[i] = 0.05f * sqrtf(-2.f * logf(u1)) * cosf(6.2831853f * u2);
+        }
+        hipMemcpy(dA, h, bytes, hipMemcpyHostToDevice);
+        free(h);
+    }
+    printf("data: %s\n", g_random ? "random normals" : "zeros / small constants");
     const int steps = 2000;
     run<8, 4, false, false>("const A, const B", 2, dA, dout, steps, bytes);
     run<8, 4, false, true>("const A, LDS B", 2, dA, dout, steps, bytes);
