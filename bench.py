@@ -1,21 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- BASELINE metric on MI355X: SDF test points/sec (+ per-frame update ms) for 3-D
-640x480 synthetic depth and a 256^3 query grid.
+640x480 synthetic depth and a 256^3 query grid (SURVEY.md 8d, config 4, F = 5 frames).
 
 A "step" is one GPisMap3 test() pass over the query grid, inputs already resident in HBM
-(gpis3_test_device).  update() of the synthetic frames is timed separately during set-up and
-reported as update_ms_per_frame.  With N > 1 ranks (torchrun, one process per GPU, RCCL) the grid is
-cut into N contiguous slabs (strong scaling); every rank builds the same map, evaluates its slab,
-and the slabs are gathered on rank 0 with one RCCL gather inside the timed region.
+(gpis3_test_device).  update() of the synthetic frames is timed during set-up (median of frames 2..F,
+with the per-phase split) and reported beside it.
+
+`python bench.py --gpus N` works as typed: for N > 1 the parent starts N ranks with
+torch.distributed.run BEFORE it touches the GPU and relays rank 0's JSON line; launched by torchrun
+itself (RANK/WORLD_SIZE set) it is one rank.  One process per GPU over RCCL: the grid is dealt to the
+ranks in 64 K-query blocks round-robin (strong scaling), every rank evaluates its blocks, the results
+are assembled on rank 0 with one transfer per rank inside the timed region.  Training is replicated
+(--train replicated, default: no exchange) or sharded (--train sharded: each rank factorises its
+share of the frame's clusters, the packed models are all-gathered).
 
 Prints ONE JSON line on rank 0 carrying `roofline` (dominant kernel = K4 ongpis_eval_kernel,
-MFMA/FLOP-bound; achieved = algorithmic flops / time inside the K4 launches measured with HIP
-events on the launch stream) and `cpu_baseline` (CPU oracle timed on the host cores, rank 0, on a
-bounded subsample of the same grid).
+MFMA/FLOP-bound; achieved = algorithmic flops / time inside the K4 launches measured with HIP events
+on the launch stream), `cpu_baseline` (CPU oracle on the host cores, rank 0, N = 1, bounded
+subsample, median of 3) and the sub-records `update_roofline` (K3 on the frame's clusters), `stress`
+(BASELINE config 5: 50 000 clusters x 64 points, train + predict) and `value_host_api` (the same pass
+through the host-pointer API the mex gateway uses, PCIe included).
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -23,20 +33,46 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-import numpy as np  # noqa: E402
 
-
-def main():
+def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--frames", type=int, default=2, help="synthetic depth frames fused before testing")
+    ap.add_argument("--frames", type=int, default=5, help="synthetic depth frames fused before testing (SURVEY 8d: F = 5)")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
-    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: results staged through host memory)")
-    ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline runs on a sample^3 subgrid (0 = skip)")
-    args = ap.parse_args()
+    ap.add_argument("--train", default="replicated", choices=["replicated", "sharded"], help="multi-rank update(): every rank trains everything, or its K^3-balanced share + all-gather of the models")
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: transfers staged through host memory)")
+    ap.add_argument("--block", type=int, default=65536, help="queries per block of the block-cyclic cut")
+    ap.add_argument("--cpu-sample", type=int, default=40, help="CPU baseline runs on a sample^3 subgrid (0 = skip)")
+    ap.add_argument("--stress", type=int, default=50000, help="clusters of the stress sub-record (0 = skip)")
+    ap.add_argument("--no-host-api", action="store_true", help="skip the value_host_api pass")
+    return ap.parse_args()
 
+
+def self_launch(args):
+    """N > 1 without a launcher: start the ranks as children of a process that has not touched the GPU."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
+
+
+def file_sha(path):
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def main():
+    args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     import gpismap_amd
@@ -46,55 +82,64 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     if not torch.cuda.is_available() or gpismap_amd.device_count() < 1:
         raise SystemExit("bench.py needs a HIP device: gpismap_amd has no CPU fallback")
     if args.backend == "gloo":
         local_rank = local_rank % torch.cuda.device_count()      # rehearsal: several ranks may share a GPU
     torch.cuda.set_device(local_rank)
+    gpismap_amd.set_device(local_rank)                           # the library selects its device explicitly
     dev = torch.device("cuda", local_rank)
+    host_staged = args.backend == "gloo"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "gloo":
+        if host_staged:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    sharded = world > 1 and args.train == "sharded"
 
     # ---- set-up (untimed): fuse the synthetic frames; time update() per frame ----
     gm = gpismap_amd.GPisMap3()          # default camera 640x480, fx=fy=568, cx=310, cy=224
-    upd_ms = []
+    assert gm.device() == local_rank
+    gm.set_profile(True)                 # hipEvents around the K4 / K3 launches
+    if sharded:
+        gm.set_shard(rank, world)
+    upd_ms, phases, k3 = [], [], []
+    exch_bytes = 0
     for f in range(args.frames):
         depth = replay.synthetic_depth(f)
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         gm.update(depth, replay.IDENTITY_POSE)
+        if sharded:
+            _, nb = sharding.exchange_models(gm, world, rank, dev, host_staged)
+            exch_bytes += nb
         upd_ms.append((time.perf_counter() - t0) * 1e3)
+        s = gm.stats()
+        phases.append([s["upd_preproc_ms"], s["upd_obsgp_train_ms"], s["upd_reeval_ms"], s["upd_eval_ms"], s["upd_gps_ms"]])
+        k3.append(dict(ms=s["last_train_ms"], flops=s["last_train_flops"], bytes=s["last_train_bytes"],
+                       clusters=int(s["last_train_jobs"]), maxK=int(s["last_train_maxK"])))
     st0 = gm.stats()
 
     n_total = args.grid ** 3
     grid = replay.synthetic_grid(args.grid)                    # [n,3] float32, x fastest
-    lo, hi = sharding.slab_bounds(n_total, world, rank)
-    x = torch.from_numpy(grid[lo:hi]).to(dev)                  # resident in HBM before timing
-    full = None
-    if world > 1 and rank == 0:
-        full = torch.zeros((n_total, 8), dtype=torch.float32, device=dev)   # the assembled map
-        res = full[lo:hi]
-    else:
-        res = torch.zeros((hi - lo, 8), dtype=torch.float32, device=dev)
+    x = torch.from_numpy(sharding.take_blocks(grid, world, rank, args.block)).to(dev)   # resident in HBM before timing
+    n_loc = x.shape[0]
+    res = torch.zeros((n_loc, 8), dtype=torch.float32, device=dev)
+    full = torch.zeros((n_total, 8), dtype=torch.float32, device=dev) if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream().cuda_stream
-    gm.set_profile(True)                                       # hipEvents around the K4 launches
 
     def step():
-        gm.test_device(x.data_ptr(), hi - lo, res.data_ptr(), stream)
+        gm.test_device(x.data_ptr(), n_loc, res.data_ptr(), stream)
         if world > 1:
-            if args.backend == "gloo":     # rehearsal path: host staging (gloo has no device P2P)
+            if host_staged:                # rehearsal path: host staging (gloo has no device P2P)
                 torch.cuda.synchronize()
-                got = sharding.gather_slabs(res.cpu(), n_total, world, rank, dst=0)
+                got = sharding.gather_blocks(res.cpu(), n_total, world, rank, dst=0, block=args.block)
                 if rank == 0:
                     full.copy_(got)
             else:
-                sharding.gather_slabs(res, n_total, world, rank, dst=0, out=full)
+                sharding.gather_blocks(res, n_total, world, rank, dst=0, out=full, block=args.block)
 
     def barrier():
         if world > 1:
@@ -104,10 +149,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    k4_ms = 0.0
-    flops = 0.0
-    launches = 0
-    evals = 0
+    k4_ms = flops = launches = evals = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -116,62 +158,114 @@ def main():
         evals += s["last_test_evals"]
     barrier()
     elapsed = time.perf_counter() - t0
+    evals_rank = evals / max(1, args.steps)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        ev = torch.tensor([evals_rank, k4_ms / max(1, args.steps)], dtype=torch.float64, device="cpu" if host_staged else dev)
+        evs = [torch.zeros_like(ev) for _ in range(world)]
+        dist.all_gather(evs, ev)
+        per_rank = [[float(v) for v in e.cpu()] for e in evs]
+    else:
+        per_rank = [[evals_rank, k4_ms / max(1, args.steps)]]
 
-    if args.backend == "gloo" and world > 1 and rank == 0:
+    if host_staged and world > 1 and rank == 0:
         # rehearsal only: the assembled map must equal a single-rank pass over the whole grid, bit for bit
         xf = torch.from_numpy(grid).to(dev)
         ref = torch.zeros((n_total, 8), dtype=torch.float32, device=dev)
         gm.test_device(xf.data_ptr(), n_total, ref.data_ptr(), stream)
         torch.cuda.synchronize()
         same = bool(torch.equal(ref.view(torch.int32), full.view(torch.int32)))
-        print("rehearsal (%d ranks, gloo staging): assembled map identical to a single-rank pass: %s" % (world, same), file=sys.stderr)
+        print("rehearsal (%d ranks, %s training, gloo staging): assembled map identical to a single-rank pass: %s"
+              % (world, args.train, same), file=sys.stderr)
         if not same:
             raise SystemExit("multi-rank assembly differs from the single-rank result")
         del xf, ref
+
+    # ---- value_host_api: the same pass through gpis3_test with HOST pointers (what the mex gateway calls) ----
+    host_api = None
+    if rank == 0 and world == 1 and not args.no_host_api:
+        hres = np.zeros((n_total, 8), dtype=np.float32)
+        gm.test(grid, hres)                                    # warm the staging buffers
+        t0 = time.perf_counter()
+        gm.test(grid, hres)
+        host_api = n_total / (time.perf_counter() - t0)
+        del hres
+
+    # ---- stress sub-record: BASELINE config 5 through the kernel-level C-ABI ----
+    stress = None
+    if args.stress > 0:
+        stress = run_stress(args, world, rank, dev, host_staged)
 
     # ---- CPU baseline: the oracle on the host cores, bounded subsample of the same grid ----
     cpu = None
     if rank == 0 and world == 1 and args.cpu_sample > 0:   # N = 1 only (bench contract)
         import oracle_lib
+        # timed in the oracle's "natural" arithmetic = the reference's own algorithm (Cholesky + substitution per query,
+        # OnGPIS.cpp:177-216); the "tiled" mode carries an explicit inverse that only exists for the GPU formulation
+        oracle_lib.set_arith_mode("natural")
         om = oracle_lib.OracleMap3()
-        t0 = time.perf_counter()
+        cu = []
         for f in range(args.frames):
+            t0 = time.perf_counter()
             om.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
-        cpu_upd_ms = (time.perf_counter() - t0) * 1e3 / args.frames
+            cu.append((time.perf_counter() - t0) * 1e3)
         m = args.cpu_sample
         idx = np.linspace(0, args.grid - 1, m).round().astype(np.int64)
         sub = grid.reshape(args.grid, args.grid, args.grid, 3)[np.ix_(idx, idx, idx)].reshape(-1, 3)
-        t0 = time.perf_counter()
-        ro = om.test(sub)
-        cpu_s = time.perf_counter() - t0
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ro = om.test(sub)
+            ts.append(time.perf_counter() - t0)
         cores = os.cpu_count() or 1
+        cpu_s = float(np.median(ts))
+        oracle_lib.set_arith_mode("tiled")
         cpu = {"value": sub.shape[0] / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
-               "sample": "%d^3 subsample of the same %d^3 grid after the same %d frames (CPU oracle, %d threads); "
-                         "update %.0f ms/frame" % (m, args.grid, args.frames, cores, cpu_upd_ms),
-               "update_ms_per_frame": cpu_upd_ms}
-        # sanity: the GPU result on the sample must match the oracle
-        if world == 1:
-            flat = (idx[:, None, None] * args.grid + idx[None, :, None]) * args.grid + idx[None, None, :]
-            rg = res[torch.from_numpy(flat.reshape(-1)).to(dev)].cpu().numpy()
-            fl = om.test_flags(sub)
-            okm = (fl & 6) == 0
-            cpu["sdf_rmse_vs_oracle"] = float(np.sqrt(np.mean((rg[okm, 0] - ro[okm, 0]) ** 2)))
+               "sample": "%d^3 subsample of the same %d^3 grid after the same %d frames (CPU oracle in its natural-order arithmetic = the "
+                         "reference's substitution algorithm, %d threads), median of 3 passes; update median of frames 2..%d"
+                         % (m, args.grid, args.frames, cores, args.frames),
+               "update_ms_per_frame": float(np.median(cu[1:] if len(cu) > 1 else cu)), "update_ms_frames": cu,
+               "test_s_passes": ts}
+        # parity on the sample: ALL sampled queries, nothing masked; flagged = on one of the reference's discontinuities.
+        # (a) against the natural-order run just timed (independent summation order, its own map);
+        flat = (idx[:, None, None] * args.grid + idx[None, :, None]) * args.grid + idx[None, None, :]
+        rg = res[torch.from_numpy(flat.reshape(-1)).to(dev)].cpu().numpy()
+        fl = om.test_flags(sub)
+        cpu["sdf_rmse_vs_oracle_natural_order"] = float(np.sqrt(np.mean((rg[:, 0].astype(np.float64) - ro[:, 0]) ** 2)))
+        cpu["map_points_oracle_natural_order"] = om.num_points()
+        cpu["branch_ambiguous_in_sample"] = int(((fl & 6) != 0).sum())
+        # (b) bit-exactness against the tiled-order oracle (the order the kernels implement) on a 16^3 sub-sample
+        ot = oracle_lib.OracleMap3()
+        for f in range(args.frames):
+            ot.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+        i2 = np.linspace(0, m - 1, 16).round().astype(np.int64)
+        pick = ((i2[:, None, None] * m + i2[None, :, None]) * m + i2[None, None, :]).reshape(-1)
+        rt = ot.test(sub[pick])
+        cpu["sdf_rmse_vs_oracle"] = float(np.sqrt(np.mean((rg[pick, 0].astype(np.float64) - rt[:, 0]) ** 2)))
+        cpu["identical_rows_vs_oracle"] = float(np.mean(np.all(rg[pick] == rt, axis=1)))
+        cpu["map_points_oracle"] = ot.num_points()
 
     if rank == 0:
         n_pts = n_total * args.steps
         value = n_pts / elapsed
         tflops = (flops / 1e12) / (k4_ms / 1e3) if k4_ms > 0 else None
-        # HBM bytes per K4 launch: measured with rocprofv3 PMC counters in separate passes of this command
-        # (profiles/README.md); a committed measurement, not collected live
+        # HBM bytes per K4 launch: rocprofv3 PMC passes of this command (tools/measure_traffic.sh), valid only for the
+        # kernel source they were measured on
         traffic = None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k4_traffic.json")
-        if os.path.exists(tpath) and args.grid == 256 and args.frames == 2:
+        tpath = os.path.join(ROOT, "profiles", "r02_k4_traffic.json")
+        if os.path.exists(tpath):
             with open(tpath) as fh:
-                traffic = json.load(fh).get("hbm_bytes_per_launch")
+                tj = json.load(fh)
+            if (tj.get("ongpis_test_sha") == file_sha(os.path.join(ROOT, "gpismap_amd", "csrc", "ongpis_test.hip"))
+                    and tj.get("grid") == args.grid and tj.get("frames") == args.frames):
+                traffic = tj.get("hbm_bytes_per_launch")
+        med = lambda a: float(np.median(a[1:] if len(a) > 1 else a))
+        ph = np.array(phases)
+        ksel = k3[1:] if len(k3) > 1 else k3
+        k3_ms = float(np.median([k["ms"] for k in ksel]))
+        k3_fl = float(np.median([k["flops"] for k in ksel]))
         out = {
             "metric": "sdf_test_points_per_sec",
             "value": value,
@@ -189,21 +283,94 @@ def main():
                                    "%d^3 SDF query grid over [-0.6,0.6]x[-0.45,0.45]x[0.85,1.15] m" % (args.frames, args.grid),
                        "frames": args.frames, "grid": args.grid,
                        "clusters": int(st0["clusters"]), "map_points": gm.num_points(),
-                       "parallelism": "replicated map, query slabs per rank, RCCL gather" if world > 1 else "single GPU"},
-            "update_ms_per_frame": float(np.mean(upd_ms)),
+                       "parallelism": ("%s training, query blocks of %d dealt round-robin to %d ranks, RCCL point-to-point gather"
+                                       % (args.train, args.block, world)) if world > 1 else "single GPU"},
+            "update_ms_per_frame": med(upd_ms),
             "update_ms_frames": upd_ms,
-            "gp_evals_per_point": evals / (hi - lo) / args.steps,
+            "update_phases_ms": dict(zip(["preproc", "obsgp_train", "reeval_points", "new_points", "update_gps"],
+                                         [float(v) for v in (np.median(ph[1:], axis=0) if len(ph) > 1 else ph[0])])),
+            "gp_evals_per_point": sum(p[0] for p in per_rank) / n_total,
+            "per_rank": {"gp_evals": [p[0] for p in per_rank], "k4_ms_per_step": [p[1] for p in per_rank]},
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": (tflops / 157.3) if tflops else None, "traffic": traffic,
                          "kernel": "ongpis_eval_kernel (K4)", "k4_ms_per_step": k4_ms / args.steps,
                          "k4_launches_per_step": launches / args.steps,
                          "algorithmic_flops_per_step": flops / args.steps,
                          "model_bytes": st0["model_bytes"]},
+            "update_roofline": {"kernel": "K6 gather + kernel build + K3 Cholesky + K3b inverse", "bound": "mfma",
+                                "ms_per_frame": k3_ms, "algorithmic_flops_per_frame": k3_fl,
+                                "achieved": (k3_fl / 1e12) / (k3_ms / 1e3) if k3_ms > 0 else None, "peak": 157.3, "unit": "TFLOP/s",
+                                "clusters": ksel[-1]["clusters"], "max_K": max(k["maxK"] for k in ksel),
+                                "note": "flops = sum K^3/3 + 2 K^2 over the clusters retrained per frame (SURVEY 8d); the inverse adds another K^3/3 not counted"},
+            "exchange_bytes_per_frame": (exch_bytes / max(1, args.frames)) if sharded else 0,
+            "value_host_api": host_api,
+            "stress": stress,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def run_stress(args, world, rank, dev, host_staged):
+    """BASELINE config 5: NCL clusters x 64 points (K = 256).  Training is sharded over the ranks (contiguous cluster
+    ranges: all clusters cost the same), the packed models are all-gathered, every rank then predicts 64 queries per
+    cluster for the clusters of its RIGHT neighbour (so predictions run on exchanged models).  Returns the record on rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import gpismap_amd
+    from gpismap_amd import sharding
+    import replay
+    from test_gpu_ongpis import soa9
+    ncl = args.stress
+    rng = np.random.default_rng(355)
+    pos, grad, val, sx, sg = replay.stress_clusters(ncl, rng)
+    xq_all = replay.stress_queries(pos, ncl, 64, rng)
+    lo, hi = (ncl * rank) // world, (ncl * (rank + 1)) // world
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    sl = slice(lo * 64, hi * 64)
+    off = (np.arange(hi - lo + 1) * 64).astype(np.int32)
+    ids = np.arange((hi - lo) * 64, dtype=np.int32)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    models = st.train(soa9(3, pos[sl], grad[sl], val[sl], sx[sl], sg[sl]), off, ids)
+    train_wall = (time.perf_counter() - t0) * 1e3
+    train_ms = st.last_ms()[0]
+    t0 = time.perf_counter()
+    ids_by_rank, nbytes = sharding.exchange_store_models(st, models, world, rank, dev, host_staged)
+    torch.cuda.synchronize()
+    exch_ms = (time.perf_counter() - t0) * 1e3 if world > 1 else 0.0
+    nb = (rank + 1) % world
+    nlo, nhi = (ncl * nb) // world, (ncl * (nb + 1)) // world
+    xq = xq_all[nlo * 64:nhi * 64]
+    jq = np.arange(xq.shape[0], dtype=np.int32)
+    jm = np.repeat(ids_by_rank[nb], 64).astype(np.int32)
+    out = st.eval(xq, jq, jm)
+    out = st.eval(xq, jq, jm)
+    pred_ms = st.last_ms()[1]
+    finite = bool(np.all(np.isfinite(out)))
+    K = 256.0
+    t = torch.tensor([train_ms, exch_ms, pred_ms, train_wall], dtype=torch.float64)
+    if world > 1:
+        tt = t.clone() if host_staged else t.to(dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        t = tt.cpu()
+    train_ms, exch_ms, pred_ms, train_wall = [float(v) for v in t]
+    if rank != 0:
+        return None
+    tr_flops = ncl * (K ** 3 / 3 + 2 * K * K)
+    tr_bytes = ncl * (36.0 * 64 + 4.0 * (K * (K + 1) / 2 + K))
+    pr_flops = ncl * 64 * (4.0 * K * K + 8.0 * K + 25.0 * 64)
+    return {"workload": "BASELINE config 5: %d clusters x 64 points, K = 256, default_rng(355); %d rank(s), training sharded by cluster range, "
+                        "packed models all-gathered, 64 queries per cluster" % (ncl, world),
+            "clusters": ncl, "train_ms": train_ms, "train_tflops": tr_flops / 1e12 / (train_ms / 1e3),
+            "train_gbs_algorithmic": tr_bytes / 1e9 / (train_ms / 1e3), "train_wall_ms_incl_allocation": train_wall,
+            "exchange_ms": exch_ms, "exchange_bytes_received_per_rank": nbytes,
+            "predict_ms": pred_ms, "predict_evaluations": ncl * 64, "predict_tflops": pr_flops / 1e12 / (pred_ms / 1e3),
+            "finite": finite}
 
 
 if __name__ == "__main__":

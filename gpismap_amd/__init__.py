@@ -44,6 +44,15 @@ def lib():
     L.gpis_version.restype = C.c_char_p
     L.gpis_set_device.argtypes = [C.c_int]
     L.gpis3_device.argtypes = [vp]
+    L.gpis3_set_shard.argtypes = [vp, C.c_int, C.c_int]
+    L.gpis3_shard_info.argtypes = [vp, ip, C.c_int]
+    L.gpis3_shard_packed_bytes.argtypes = [vp]; L.gpis3_shard_packed_bytes.restype = C.c_longlong
+    L.gpis3_shard_pack.argtypes = [vp, vp, C.c_longlong, vp]
+    L.gpis3_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int, C.c_longlong, vp]
+    L.gpis3_shard_finish.argtypes = [vp]
+    L.gpis_ongpis_packed_bytes.argtypes = [vp, ip, C.c_int]; L.gpis_ongpis_packed_bytes.restype = C.c_longlong
+    L.gpis_ongpis_pack.argtypes = [vp, ip, C.c_int, vp, C.c_longlong, vp]
+    L.gpis_ongpis_unpack.argtypes = [vp, vp, C.c_int, C.c_longlong, ip, vp]
     L.gpis2_device.argtypes = [vp]
     L.gpis3_create.restype = vp
     L.gpis3_create.argtypes = [C.POINTER(gpis_cam)]
@@ -115,7 +124,7 @@ class GPisMap3:
     STAT_KEYS = ("obsgp_groups", "obsgp_queries", "clusters_trained", "late_reevals", "clusters",
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
-                 "upd_gps_ms")
+                 "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK")
 
     def __init__(self, cam6=None):
         self.L = lib()
@@ -164,6 +173,30 @@ class GPisMap3:
     def device(self):
         return self.L.gpis3_device(self.h)
 
+    # ---- sharded training (include/gpismap_amd.h, gpis3_set_shard ...) ----
+    def set_shard(self, rank, world):
+        _check(self.L.gpis3_set_shard(self.h, int(rank), int(world)), "gpis3_set_shard")
+        self._world = int(world)
+
+    def shard_info(self):
+        w = getattr(self, "_world", 1)
+        out = np.zeros(2 + w, dtype=np.int32)
+        _check(self.L.gpis3_shard_info(self.h, _p(out, C.c_int), 2 + w), "gpis3_shard_info")
+        return int(out[0]), int(out[1]), [int(v) for v in out[2:]]
+
+    def shard_packed_bytes(self):
+        return int(self.L.gpis3_shard_packed_bytes(self.h))
+
+    def shard_pack(self, d_buf_ptr, stride, stream=0):
+        _check(self.L.gpis3_shard_pack(self.h, C.c_void_p(d_buf_ptr), int(stride), C.c_void_p(stream)), "gpis3_shard_pack")
+
+    def shard_unpack(self, owner, d_buf_ptr, n, stride, stream=0):
+        _check(self.L.gpis3_shard_unpack(self.h, int(owner), C.c_void_p(d_buf_ptr), int(n), int(stride), C.c_void_p(stream)),
+               "gpis3_shard_unpack")
+
+    def shard_finish(self):
+        _check(self.L.gpis3_shard_finish(self.h), "gpis3_shard_finish")
+
     def num_points(self):
         return self.L.gpis3_num_points(self.h)
 
@@ -182,8 +215,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 17)()
-        _check(self.L.gpis3_stats(self.h, a, 17), "gpis3_stats")
+        a = (C.c_double * 21)()
+        _check(self.L.gpis3_stats(self.h, a, 21), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def set_profile(self, on=True):
@@ -334,6 +367,22 @@ class OnGPIS:
         _check(self.L.gpis_ongpis_eval(self.h, _p(xq), xq.shape[0], _p(job_q, C.c_int), _p(job_model, C.c_int), job_q.size,
                                        _p(out)), "gpis_ongpis_eval")
         return out
+
+    def packed_bytes(self, models):
+        models = np.ascontiguousarray(models, dtype=np.int32)
+        return int(self.L.gpis_ongpis_packed_bytes(self.h, _p(models, C.c_int), models.size))
+
+    def pack(self, models, d_buf_ptr, stride, stream=0):
+        models = np.ascontiguousarray(models, dtype=np.int32)
+        _check(self.L.gpis_ongpis_pack(self.h, _p(models, C.c_int), models.size, C.c_void_p(d_buf_ptr), int(stride), C.c_void_p(stream)),
+               "gpis_ongpis_pack")
+
+    def unpack(self, d_buf_ptr, n, stride, models=None, stream=0):
+        """records -> predict-only models; returns their ids (new ones unless `models` names slots to reuse)."""
+        ids = np.full(n, -1, dtype=np.int32) if models is None else np.ascontiguousarray(models, dtype=np.int32).copy()
+        _check(self.L.gpis_ongpis_unpack(self.h, C.c_void_p(d_buf_ptr), int(n), int(stride), _p(ids, C.c_int), C.c_void_p(stream)),
+               "gpis_ongpis_unpack")
+        return ids
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

@@ -20,6 +20,12 @@ int gpis2_impl_fail(GPisMap* m);
 int gpis3_impl_update_fail(GPisMap3* m);
 int gpis2_impl_update_fail(GPisMap* m);
 int gpis3_impl_device(GPisMap3* m);
+int gpis3_impl_set_shard(GPisMap3* m, int rank, int world);
+int gpis3_impl_shard_info(GPisMap3* m, int* out, int n);
+long long gpis3_impl_shard_packed_bytes(GPisMap3* m);
+int gpis3_impl_shard_pack(GPisMap3* m, void* d_buf, long long stride, void* stream);
+int gpis3_impl_shard_unpack(GPisMap3* m, int owner, const void* d_buf, int n, long long stride, void* stream);
+int gpis3_impl_shard_finish(GPisMap3* m);
 int gpis2_impl_device(GPisMap* m);
 
 extern "C" {
@@ -79,6 +85,21 @@ int gpis3_test_device(void* m, const float* d_x, int n, float* d_res, void* stre
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis3_device(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_device((GPisMap3*)m); }
+int gpis3_set_shard(void* m, int rank, int world) {
+    if (!m || world < 1 || rank < 0 || rank >= world) return GPIS_ERR_ARG;
+    return gpis3_impl_set_shard((GPisMap3*)m, rank, world);
+}
+int gpis3_shard_info(void* m, int* out, int n) { if (!m || !out) return GPIS_ERR_ARG; return gpis3_impl_shard_info((GPisMap3*)m, out, n); }
+long long gpis3_shard_packed_bytes(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_packed_bytes((GPisMap3*)m); }
+int gpis3_shard_pack(void* m, void* d_buf, long long stride, void* stream) {
+    if (!m || stride < 256) return GPIS_ERR_ARG;
+    return gpis3_impl_shard_pack((GPisMap3*)m, d_buf, stride, stream);
+}
+int gpis3_shard_unpack(void* m, int owner, const void* d_buf, int n, long long stride, void* stream) {
+    if (!m || stride < 256 || n < 0) return GPIS_ERR_ARG;
+    return gpis3_impl_shard_unpack((GPisMap3*)m, owner, d_buf, n, stride, stream);
+}
+int gpis3_shard_finish(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_finish((GPisMap3*)m); }
 int gpis3_num_points(void* m) {
     if (!m) return GPIS_ERR_ARG;
     std::vector<float> p; ((GPisMap3*)m)->getAllPoints(p); return (int)(p.size() / 3);
@@ -211,6 +232,7 @@ int gpis_ongpis_get_model(void* s, int model, float* L, float* alpha, int* gidx)
     OnHandle* h = (OnHandle*)s;
     const ClusterModel* m = h->st.model(model);
     if (!m || !m->base) return GPIS_ERR_ARG;
+    if (!m->L) return GPIS_ERR_STATE;   // imported (predict-only) model: no factor on this rank
     if (L) GPIS_HIP(hipMemcpyAsync(L, m->L, sizeof(float) * (size_t)m->ld * m->ld, hipMemcpyDeviceToHost, h->s));
     if (alpha) GPIS_HIP(hipMemcpyAsync(alpha, m->alpha, sizeof(float) * m->K, hipMemcpyDeviceToHost, h->s));
     if (gidx) GPIS_HIP(hipMemcpyAsync(gidx, m->gidx, sizeof(int) * m->N, hipMemcpyDeviceToHost, h->s));
@@ -233,6 +255,20 @@ int gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const i
     GPIS_HIP(hipMemcpyAsync(out8, h->d_out, sizeof(float) * no, hipMemcpyDeviceToHost, h->s));
     GPIS_HIP(hipStreamSynchronize(h->s));
     return GPIS_OK;
+}
+long long gpis_ongpis_packed_bytes(void* s, const int* models, int n) {
+    if (!s || (!models && n > 0) || n < 0) return GPIS_ERR_ARG;
+    return (long long)((OnHandle*)s)->st.packed_bytes(models, n);
+}
+int gpis_ongpis_pack(void* s, const int* models, int n, void* d_buf, long long stride, void* stream) {
+    if (!s || !models || !d_buf || n < 0 || stride < 256) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    return h->st.pack_models(models, n, d_buf, (size_t)stride, stream ? (hipStream_t)stream : h->s);
+}
+int gpis_ongpis_unpack(void* s, const void* d_buf, int n, long long stride, int* models_inout, void* stream) {
+    if (!s || !d_buf || !models_inout || n < 0 || stride < 256) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    return h->st.unpack_models(d_buf, n, (size_t)stride, models_inout, stream ? (hipStream_t)stream : h->s);
 }
 int gpis_ongpis_set_exp_table(void* s, int on) {
     if (!s) return GPIS_ERR_ARG;

@@ -94,6 +94,13 @@ struct GPisMap3::Impl {
     double stat_model_bytes = 0;  // sum over live models of 4 [dN + K + K(K+1)/2] (SURVEY 8d model_bytes)
     float last_update_ms[6] = {0, 0, 0, 0, 0, 0};
 
+    // sharded training (gpis3_set_shard): owner rank of every cluster job of the last update(), in job order
+    int shard_rank = 0, shard_world = 1;
+    struct ShardJob { int slot, n, ng, owner; };
+    std::vector<ShardJob> shard_jobs;
+    bool table_pending = false;   // update() trained the local share only: the cluster table waits for the exchange
+    void build_cluster_table();
+
     Impl(const GPisMap3Param& par, const camParam& c)
         : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
           mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
@@ -515,6 +522,8 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
 
 // -------------------------------------------------------------------- updateGPs ----
 void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
+    shard_jobs.clear();
+    table_pending = false;
     T3::Set updateSet(activeSet);
     std::vector<int> qs;
     for (int a : activeSet) {
@@ -555,12 +564,38 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
             }
             int rc = store.upload_points(soa.data(), (int)np, stream);
-            if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
+            if (shard_world > 1) {
+                // Greedy longest-processing-time partition of the frame's clusters by their K^3 factorisation cost
+                // (ties by job order): every rank computes the same owners and trains only its own share.
+                std::vector<int> ord(jobs.size());
+                for (size_t i = 0; i < ord.size(); ++i) ord[i] = (int)i;
+                auto cost = [&](int j) { const double K = jobs[j].n + 3.0 * jobs[j].ng; return K * K * K; };
+                std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return cost(a) > cost(b); });
+                std::vector<double> load(shard_world, 0.0);
+                std::vector<int> owner(jobs.size(), 0);
+                for (int j : ord) {
+                    int best = 0;
+                    for (int r = 1; r < shard_world; ++r) if (load[r] < load[best]) best = r;
+                    owner[j] = best; load[best] += cost(j);
+                }
+                std::vector<TrainJob> mine;
+                for (size_t j = 0; j < jobs.size(); ++j) {
+                    shard_jobs.push_back({jobs[j].model, jobs[j].n, jobs[j].ng, owner[j]});
+                    if (owner[j] == shard_rank) mine.push_back(jobs[j]);
+                }
+                if (rc == GPIS_OK && !mine.empty()) rc = store.train_batch(mine, ids, stream);
+                table_pending = true;
+            } else if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
         }
     }
     activeSet.clear();
+    if (!table_pending) build_cluster_table();
+}
+
+void GPisMap3::Impl::build_cluster_table() {
+    table_pending = false;
 
     // cluster table for test(): every non-empty cluster cell in traversal order
     std::vector<int> cl;
@@ -661,6 +696,7 @@ bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_st
     m.fail_rc = 0;
     if (!m.ok || !d_x || !d_res || leng < 1) return false;
     if (!m.has_tree) return false;  // the reference dereferences a null tree here
+    if (m.table_pending) { m.fail_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: sharded update not finished (gpis3_shard_finish)\n"); return false; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
     m.fail_rc = 0;
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
@@ -675,6 +711,7 @@ bool GPisMap3::test(float* x, int dim, int leng, float* res) try {  // GPisMap3.
     if (x == 0 || dim != 3 || leng < 1) return false;
     if (!m.ok) { fprintf(stderr, "[gpismap_amd] GPisMap3::test: HIP device unavailable\n"); return false; }
     if (!m.has_tree) return false;
+    if (m.table_pending) { m.fail_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] GPisMap3::test: sharded update not finished (gpis3_shard_finish)\n"); return false; }
     m.fail_rc = 0;
     auto fail = [&](int rc) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::test: device path failed (%d)\n", rc); return false; };
     size_t nx = (size_t)3 * leng, nr = (size_t)8 * leng;
@@ -717,15 +754,71 @@ void GPisMap3::getAllNodes(std::vector<float>& out) try {
 // accessors used by the C-ABI (capi.cpp)
 int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
 int gpis3_impl_device(GPisMap3* g) { return g->impl()->device; }
+int gpis3_impl_set_shard(GPisMap3* g, int rank, int world) {
+    GPisMap3::Impl& m = *g->impl();
+    if (m.table_pending) return GPIS_ERR_STATE;
+    m.shard_rank = rank; m.shard_world = world;
+    return GPIS_OK;
+}
+int gpis3_impl_shard_info(GPisMap3* g, int* out, int n) {
+    GPisMap3::Impl& m = *g->impl();
+    if (n < 2 + m.shard_world) return GPIS_ERR_ARG;
+    out[0] = (int)m.shard_jobs.size(); out[1] = 0;
+    for (int r = 0; r < m.shard_world; ++r) out[2 + r] = 0;
+    for (auto& j : m.shard_jobs) { ++out[2 + j.owner]; if (j.owner == m.shard_rank) ++out[1]; }
+    return GPIS_OK;
+}
+static void shard_slots(GPisMap3::Impl& m, int owner, std::vector<int>& slots) {
+    slots.clear();
+    for (auto& j : m.shard_jobs) if (j.owner == owner) slots.push_back(j.slot);
+}
+long long gpis3_impl_shard_packed_bytes(GPisMap3* g) {
+    GPisMap3::Impl& m = *g->impl();
+    size_t mx = 256;    // every rank can size every record: N and ng of all jobs are known everywhere
+    for (auto& j : m.shard_jobs) {
+        const int K = j.n + 3 * j.ng, ld = (K + 1 + 31) / 32 * 32;
+        mx = std::max(mx, packed_model_bytes(ld, j.n));
+    }
+    return (long long)mx;
+}
+int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, long long stride, void* stream) {
+    GPisMap3::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    std::vector<int> slots;
+    shard_slots(m, m.shard_rank, slots);
+    if (slots.empty()) return GPIS_OK;
+    if (!d_buf) return GPIS_ERR_ARG;
+    return m.store.pack_models(slots.data(), (int)slots.size(), d_buf, (size_t)stride, stream ? (hipStream_t)stream : m.stream);
+}
+int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, int n, long long stride, void* stream) {
+    GPisMap3::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    if (owner < 0 || owner >= m.shard_world || owner == m.shard_rank) return GPIS_ERR_ARG;
+    std::vector<int> slots;
+    shard_slots(m, owner, slots);
+    if ((int)slots.size() != n) return GPIS_ERR_ARG;
+    if (n == 0) return GPIS_OK;
+    if (!d_buf) return GPIS_ERR_ARG;
+    return m.store.unpack_models(d_buf, n, (size_t)stride, slots.data(), stream ? (hipStream_t)stream : m.stream);
+}
+int gpis3_impl_shard_finish(GPisMap3* g) {
+    GPisMap3::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    if (!m.table_pending) return GPIS_OK;
+    m.upd_rc = 0;
+    m.build_cluster_table();
+    return m.upd_rc;
+}
 int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
-    double v[17] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[21] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
-                    m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4]};
-    for (int i = 0; i < n && i < 17; ++i) out[i] = v[i];
+                    m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
+                    m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK};
+    for (int i = 0; i < n && i < 21; ++i) out[i] = v[i];
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

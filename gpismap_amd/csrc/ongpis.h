@@ -68,6 +68,12 @@ public:
     // (device) receives 2*(1+dim) floats per job: mean(1+dim), var(1+dim).
     int eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
                   hipStream_t s);
+    // ---- multi-GPU exchange (model_pack.hip): packed records of what K4 needs from a trained model ----
+    size_t packed_bytes(const int* slots, int n) const;                 // largest record among the listed models
+    int pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s);
+    // records -> models.  slots_inout[i] < 0: a new slot is created and returned there; else that slot is (re)used.
+    // The models are predict-only (no factor, no training scratch).
+    int unpack_models(const void* d_buf, int n, size_t stride, int* slots_inout, hipStream_t s);
     const ClusterModel* model(int slot) const { return (slot >= 0 && slot < (int)models_.size() && live_[slot]) ? &models_[slot] : nullptr; }
     ClusterModel* d_models() { return d_models_; }   // device array mirroring models_
     int sync_models(hipStream_t s);                  // re-upload descriptor table if dirty
@@ -76,12 +82,14 @@ public:
     DevPool* pool() { return pool_; }
     // timing of the dominant kernels (hipEvents on the launch stream), ms of the last call
     float last_train_ms = 0.f, last_eval_ms = 0.f;
+    double last_train_flops = 0.0, last_train_bytes = 0.0;   // algorithmic: sum K^3/3 + 2K^2 ; 36 N + 4 [K(K+1)/2 + K]
+    int last_train_jobs = 0, last_train_maxK = 0;
     long long last_eval_flops = 0;
     bool profile = false;
     bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
 
 private:
-    int alloc_model(int slot, int N, int ng);
+    int alloc_model(int slot, int N, int ng, bool predict_only = false);
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc);
     int dim_;
     float scale_;
@@ -103,6 +111,8 @@ private:
 };
 
 // kernels (ongpis_train.hip / ongpis_test.hip)
+size_t packed_model_bytes(int ld, int N);
+void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slots, int n, char* d_buf, size_t stride, hipStream_t s);
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);

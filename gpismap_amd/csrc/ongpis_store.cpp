@@ -51,7 +51,7 @@ void OnGPISStore::release_slot(int s) {
 
 size_t OnGPISStore::device_bytes() const { return pool_bytes(pool_); }
 
-int OnGPISStore::alloc_model(int slot, int N, int ng) {
+int OnGPISStore::alloc_model(int slot, int N, int ng, bool predict_only) {
     ClusterModel& m = models_[slot];
     int K = N + dim_ * ng;
     int ld = (int)align_up((size_t)K + 1, 32);
@@ -66,9 +66,21 @@ int OnGPISStore::alloc_model(int slot, int N, int ng) {
     size_t oT = align_up(oG + szG, 256), szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
     size_t oXt = align_up(oT + szT, 256), oZt = align_up(oXt + szT, 256);   // explicit inverse, re-tiled, and its transposed tiles
     size_t total = align_up(oZt + szT, 256);
+    if (predict_only) {   // imported model: only what K4 reads (rowinfo, x4, Xt)
+        oR = 0; oX = align_up(oR + szR, 256); oXt = align_up(oX + szX, 256);
+        total = align_up(oXt + szT, 256);
+    }
     if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
     char* base = (char*)pool_alloc(pool_, total);
     if (!base) return GPIS_ERR_HIP;
+    if (predict_only) {
+        std::memset(&m, 0, sizeof(ClusterModel));
+        m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
+        m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
+        m.base = base;
+        dirty_ = true;
+        return GPIS_OK;
+    }
     m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
     m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
     m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
@@ -177,6 +189,13 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         GPIS_HIP(hipMalloc(&d_jobs_, sizeof(int) * (size_t)cap));
         cap_jobs_ = cap;
     }
+    last_train_flops = 0.0; last_train_bytes = 0.0; last_train_jobs = nj; last_train_maxK = 0;
+    for (int j = 0; j < nj; ++j) {
+        const double N = tab[4 * j + 2], K = N + (double)dim_ * tab[4 * j + 3];
+        last_train_flops += K * K * K / 3.0 + 2.0 * K * K;
+        last_train_bytes += 36.0 * N + 4.0 * (K * (K + 1) / 2.0 + K);
+        last_train_maxK = std::max(last_train_maxK, (int)K);
+    }
     // K3b work list: one wavefront per (job, block column), big clusters and long columns first
     std::vector<int> work;
     for (int j = 0; j < nj; ++j) {
@@ -226,6 +245,61 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     GPIS_HIP(hipStreamSynchronize(s));
     if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
     return deferred_rc;
+}
+
+size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
+    size_t mx = 0;
+    for (int i = 0; i < n; ++i) {
+        const ClusterModel* m = model(slots[i]);
+        if (m && m->base) mx = std::max(mx, packed_model_bytes(m->ld, m->N));
+    }
+    return mx;
+}
+
+int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s) {
+    if (n <= 0) return GPIS_OK;
+    for (int i = 0; i < n; ++i) {
+        const ClusterModel* m = model(slots[i]);
+        if (!m || !m->base || !m->Xt || packed_model_bytes(m->ld, m->N) > stride) return GPIS_ERR_ARG;
+    }
+    int rc = sync_models(s);
+    if (rc) return rc;
+    int* d_slots = nullptr;
+    GPIS_HIP(hipMalloc(&d_slots, sizeof(int) * (size_t)n));
+    GPIS_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    model_pack_launch(true, d_models_, d_slots, n, (char*)d_buf, stride, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_slots);
+    return GPIS_OK;
+}
+
+int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slots, hipStream_t s) {
+    if (n <= 0) return GPIS_OK;
+    std::vector<int> hdr((size_t)16 * n);
+    GPIS_HIP(hipMemcpy2DAsync(hdr.data(), 64, d_buf, stride, 64, (size_t)n, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    for (int i = 0; i < n; ++i) {
+        const int* h = &hdr[(size_t)16 * i];
+        const int dim = h[0], N = h[1], ng = h[2], K = h[3], ld = h[4];
+        if (dim != dim_ || N <= 0 || ng < 0 || ng > N || K != N + dim * ng || ld != (int)align_up((size_t)K + 1, 32) ||
+            packed_model_bytes(ld, N) > stride)
+            return GPIS_ERR_ARG;
+        if (slots[i] < 0) slots[i] = new_slot();
+        else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return GPIS_ERR_ARG;
+        int rc = alloc_model(slots[i], N, ng, true);
+        if (rc) return rc;
+    }
+    int rc = sync_models(s);
+    if (rc) return rc;
+    int* d_slots = nullptr;
+    GPIS_HIP(hipMalloc(&d_slots, sizeof(int) * (size_t)n));
+    GPIS_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+    model_pack_launch(false, d_models_, d_slots, n, (char*)const_cast<void*>(d_buf), stride, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_slots);
+    return GPIS_OK;
 }
 
 // Job-level predict with host job arrays: sort by model, cut into tiles of ONGPIS_TILE_Q (16), launch per

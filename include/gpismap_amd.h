@@ -54,11 +54,31 @@ int   gpis3_update(void* map, const float* depth, int n, const float* pose12);
 int   gpis3_test(void* map, const float* x, int dim, int n, float* res);
 int   gpis3_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
 int   gpis3_device(void* map);                                 /* device the map lives on, or negative */
+/* ---- multi-GPU: sharded cluster training (one process per GPU).  Every rank runs the same update()
+ * (host logic is deterministic, so trees, cluster sets and model slots agree), but after gpis3_set_shard(rank, world)
+ * it TRAINS only its share of the frame's clusters (greedy longest-processing-time partition by K^3).  The caller then
+ * moves the packed models between the ranks (e.g. RCCL all-gather of equal-size records) and completes the update:
+ *   gpis3_update(...);                                  trains the local share, defers the cluster table
+ *   gpis3_shard_info(map, out, 2 + world)               out[0] = clusters of this frame, out[1] = local ones,
+ *                                                       out[2 + r] = clusters rank r trains
+ *   stride = max over ranks of gpis3_shard_packed_bytes(map)
+ *   gpis3_shard_pack(map, d_send, stride, stream)       local models -> records, in the frame's job order
+ *   gpis3_shard_unpack(map, r, d_recv_r, n_r, stride, stream)   for every other rank r
+ *   gpis3_shard_finish(map)                             builds the cluster table: test() is valid again
+ * With world = 1 (default) update() is complete on return and none of the calls is needed. */
+int   gpis3_set_shard(void* map, int rank, int world);
+int   gpis3_shard_info(void* map, int* out, int n);
+long long gpis3_shard_packed_bytes(void* map);
+int   gpis3_shard_pack(void* map, void* d_buf, long long stride, void* hip_stream);
+int   gpis3_shard_unpack(void* map, int owner, const void* d_buf, int n, long long stride, void* hip_stream);
+int   gpis3_shard_finish(void* map);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
-/* out[0..]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations,
- * clusters in table, GP evaluations of last test, ms in K4 of last test (profiling on), device bytes */
+/* out[0..20]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
+ * GP evaluations of last test, ms in K4 of last test (profiling on), device bytes, algorithmic flops of last test, K4 launches,
+ * ms in K6+K3+K3b of last update (profiling on), model bytes, update phases ms [preproc, ObsGP train, re-evaluation,
+ * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch */
 int   gpis3_stats(void* map, double* out, int n);
 int   gpis3_set_profile(void* map, int on);
 
@@ -107,6 +127,12 @@ int   gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const
                        float* out8);
 /* K4 keeps one double-precision exp per (training point, query) in an LDS table when it fits; clusters too large
  * for that recompute it per entry.  on = 0 forces the second path for every cluster (results are identical). */
+/* Packed model records for a multi-GPU exchange (what K4 needs from a trained model: 2 K^2 + 20 K bytes): pack the listed
+ * models into d_buf (n records of `stride` bytes, stride >= gpis_ongpis_packed_bytes of every sender, a multiple of 256),
+ * unpack records into predict-only models (models_inout[i] < 0: a new model is created and its id returned). */
+long long gpis_ongpis_packed_bytes(void* s, const int* models, int n);
+int   gpis_ongpis_pack(void* s, const int* models, int n, void* d_buf, long long stride, void* hip_stream);
+int   gpis_ongpis_unpack(void* s, const void* d_buf, int n, long long stride, int* models_inout, void* hip_stream);
 int   gpis_ongpis_set_exp_table(void* s, int on);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 

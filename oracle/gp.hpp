@@ -390,7 +390,7 @@ struct OnGPIS {
     std::vector<int> gidx;
     std::vector<float> L, alpha;
     std::vector<float> Linv;   // inverted 32x32 diagonal blocks of L (linalg.hpp, fwd_subst_blocked)
-    std::vector<float> X;      // tiled mode: explicit inverse X = L^-1, ROW-major K x K (lower), see train()
+    std::vector<float> X;      // tiled mode: explicit inverse X = L^-1, column-major K x K (lower), see train()
 
     OnGPIS(int dim_, float s) : dim(dim_), scale(s), three_over_scale((float)(3.0 / (double)(s * s))) {}
 
@@ -437,7 +437,7 @@ struct OnGPIS {
                 std::fill(e.begin(), e.end(), 0.f);
                 e[j] = 1.f;
                 fwd_subst_blocked(L.data() + r0 + (size_t)r0 * K, Linv.data() + (size_t)(r0 / 32) * 1024, K - r0, K, e.data() + r0, 1, K);
-                for (int i = j; i < K; ++i) X[(size_t)i * K + j] = e[i];
+                for (int i = j; i < K; ++i) X[(size_t)j * K + i] = e[i];
             }
         }
         trained = true;
@@ -501,11 +501,13 @@ struct OnGPIS {
             float m = 0.f;
             for (int r = 0; r < K; ++r) m = fmaf(alpha[r], col[r], m);
             mean[c] = m;
-            for (int r = 0; r < K; ++r) {
-                const float* xr = &X[(size_t)r * K];
-                float a = 0.f;
-                for (int k = 0; k <= r; ++k) a = fmaf(xr[k], col[k], a);
-                v[r] = a;
+            // per element r: a = 0; a = fmaf(X[r][k], col[k], a) for k = 0..r -- evaluated k-outer so that the inner loop
+            // runs over contiguous rows (same chains, vectorisable)
+            std::fill(v.begin(), v.end(), 0.f);
+            for (int k = 0; k < K; ++k) {
+                const float* xk = &X[(size_t)k * K];
+                const float ck = col[k];
+                for (int r = k; r < K; ++r) v[r] = fmaf(xk[r], ck, v[r]);
             }
             const float s = reduce_ss(K, v.data());
             if (dim == 3)  // OnGPIS.cpp:208-213

@@ -108,3 +108,29 @@ def demo2_grid():
     ys = -15.0 + 0.1 * np.arange(1, 200)
     X, Y = np.meshgrid(xs, ys, indexing="ij")
     return np.stack([X.ravel(), Y.ravel()], axis=1).astype(np.float32)
+
+
+def stress_clusters(ncl, rng):
+    """BASELINE config 5: `ncl` clusters on a 0.05 m lattice sheet, exactly 64 points each (jittered 8x8
+    grid: the 6.25 mm spacing keeps the min-distance rule), unit normals = sheet normal + N(0, 0.05^2) renormalised,
+    val = -0.2, sigx = U(1e-3, 5e-3), sigg = U(0.01, 0.1): every point carries a gradient, K = 256 for every cluster.
+    Returns pos [ncl*64, 3], grad, val, sigx, sigg (float32), cluster c = rows 64c .. 64c+63."""
+    side = int(np.ceil(np.sqrt(ncl)))
+    c = np.arange(ncl)
+    cx = (c % side) * 0.05 + 0.025
+    cy = (c // side) * 0.05 + 0.025
+    gx, gy = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
+    px = cx[:, None] - 0.025 + (gx.ravel()[None, :] + 0.5) * 0.00625 + rng.uniform(-0.001, 0.001, (ncl, 64))
+    py = cy[:, None] - 0.025 + (gy.ravel()[None, :] + 0.5) * 0.00625 + rng.uniform(-0.001, 0.001, (ncl, 64))
+    pz = rng.uniform(-0.02, 0.02, (ncl, 64))
+    pos = np.stack([px, py, pz], axis=2).reshape(-1, 3).astype(np.float32)
+    n = np.array([0.0, 0.0, 1.0]) + rng.normal(0, 0.05, (ncl * 64, 3))
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    val = np.full(ncl * 64, -0.2, dtype=np.float32)
+    return (pos, n.astype(np.float32), val, rng.uniform(1e-3, 5e-3, ncl * 64).astype(np.float32),
+            rng.uniform(0.01, 0.1, ncl * 64).astype(np.float32))
+
+
+def stress_queries(pos, ncl, nq, rng):
+    """nq queries per cluster near its points: [ncl*nq, 3]."""
+    return (pos.reshape(ncl, 64, 3)[:, rng.integers(0, 64, nq), :] + rng.normal(0, 0.005, (ncl, nq, 3))).reshape(-1, 3).astype(np.float32)

@@ -1,0 +1,57 @@
+"""Multi-rank paths on the one-GPU box: the whole bench.py (block-cyclic query cut, gather on rank 0, replicated AND
+sharded training with the packed-model all-gather, the sharded stress sub-record) run as N processes over gloo with
+transfers staged through host memory; rank 0 checks the assembled map bit for bit against a single-rank pass.  Only the
+RCCL transport itself is left to the driver's 8-GPU node."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(world, train, extra=()):
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    port = 29600 + (os.getpid() % 300) + world + (7 if train == "sharded" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--train", train,
+           "--grid", "64", "--frames", "2", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--stress", "96", "--block", "4096"] + list(extra)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "assembled map identical to a single-rank pass: True" in r.stderr, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    return json.loads(line)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("train", ["replicated", "sharded"])
+def test_bench_rehearsal_is_bit_identical(world, train):
+    d = _run(world, train)
+    assert d["n_gpus"] == world and d["config"]["grid"] == 64
+    assert len(d["per_rank"]["gp_evals"]) == world
+    ev = d["per_rank"]["gp_evals"]
+    assert max(ev) < 1.6 * (sum(ev) / world)            # the block-cyclic cut spreads the surface over the ranks
+    st = d["stress"]
+    assert st["finite"] and st["clusters"] == 96 and st["predict_evaluations"] == 96 * 64
+    if train == "sharded":
+        assert d["exchange_bytes_per_frame"] > 0
+    if world > 1:
+        assert st["exchange_bytes_received_per_rank"] > 0
+
+
+def test_bench_self_launches_from_a_plain_python_call():
+    """`python bench.py --gpus 2` as typed (no launcher): the parent must start the ranks itself."""
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--grid", "48", "--frames", "1", "--steps", "1",
+           "--warmup", "0", "--cpu-sample", "0", "--stress", "0", "--block", "4096"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["metric"] == "sdf_test_points_per_sec"

@@ -65,3 +65,41 @@ def test_stress_batch_train_and_predict():
         ref = oracle_lib.ongpis_predict(3, 0.04, pos[s], grad[s], val[s], sx[s], sg[s], xq[c * nq:(c + 1) * nq])
         got = out[c * nq:(c + 1) * nq]
         assert np.array_equal(got[:, :4], ref[:, :4]) and np.array_equal(got[:, 4:8], ref[:, 4:8])
+
+
+def test_stress_full_scale_50k_clusters():
+    """BASELINE config 5 at FULL scale on one GPU: 50 000 clusters x 64 points (K = 256), batched training and 64 queries
+    per cluster; size-independent properties on everything, a random sample of clusters bit for bit against the oracle."""
+    import gpismap_amd
+    import replay
+    from test_gpu_ongpis import soa9
+    rng = np.random.default_rng(355)
+    ncl = 50000
+    pos, grad, val, sx, sg = replay.stress_clusters(ncl, rng)
+    off = (np.arange(ncl + 1) * 64).astype(np.int32)
+    ids = np.arange(ncl * 64, dtype=np.int32)
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    models = st.train(soa9(3, pos, grad, val, sx, sg), off, ids)
+    tr_ms = st.last_ms()[0]
+    nq = 64
+    xq = replay.stress_queries(pos, ncl, nq, rng)
+    jq = np.arange(ncl * nq, dtype=np.int32)
+    jm = np.repeat(models, nq).astype(np.int32)
+    out = st.eval(xq, jq, jm)
+    ev_ms = st.last_ms()[1]
+    K = 256.0
+    print("stress FULL: %d clusters K=256: train %.1f ms (%.2f us/cluster, %.1f TFLOP/s of K^3/3+2K^2), %d evaluations in %.1f ms (%.1f TFLOP/s)"
+          % (ncl, tr_ms, 1e3 * tr_ms / ncl, ncl * (K ** 3 / 3 + 2 * K * K) / tr_ms / 1e9, out.shape[0], ev_ms,
+             ncl * nq * (4 * K * K + 8 * K + 1600) / ev_ms / 1e9))
+    assert out.shape == (ncl * nq, 8) and np.all(np.isfinite(out))
+    assert np.all(out[:, 4] <= 1.001 + 1e-6) and np.all(out[:, 5:8] <= 1875.001 + 1e-3) and np.all(out[:, 4] > -1e-3)
+    assert np.median(out[:, 4]) < 0.05 and np.median(np.abs(out[:, 0] + 0.2)) < 0.1
+    for c in rng.choice(ncl, 8, replace=False):
+        s = slice(c * 64, (c + 1) * 64)
+        g = st.model(models[c])
+        o = oracle_lib.ongpis_train(3, 0.04, pos[s], grad[s], val[s], sx[s], sg[s])
+        assert g["K"] == o["K"] == 256
+        assert np.array_equal(np.tril(g["L"][:256, :256]), np.tril(o["L"])) and np.array_equal(g["alpha"], o["alpha"])
+        ref = oracle_lib.ongpis_predict(3, 0.04, pos[s], grad[s], val[s], sx[s], sg[s], xq[c * nq:(c + 1) * nq])
+        got = out[c * nq:(c + 1) * nq]
+        assert np.array_equal(got[:, :4], ref[:, :4]) and np.array_equal(got[:, 4:8], ref[:, 4:8])

@@ -105,32 +105,60 @@ def _gloo_worker(rank, world, port, out):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     n = 1003
-    lo, hi = sharding.slab_bounds(n, world, rank)
     full = torch.arange(n * 8, dtype=torch.float32).reshape(n, 8)
-    mine = full[lo:hi].clone()                      # stands for this rank's test() output
-    got = sharding.gather_slabs(mine, n, world, rank, dst=0)
     ok = True
+    # contiguous slabs
+    lo, hi = sharding.slab_bounds(n, world, rank)
+    got = sharding.gather_slabs(full[lo:hi].clone(), n, world, rank, dst=0)
     if rank == 0:
-        ok = bool(torch.equal(got, full))
+        ok = ok and bool(torch.equal(got, full))
+    # block-cyclic cut (ragged last block, more blocks than ranks, fewer blocks than ranks)
+    for block in (64, 100, 700, 5000):
+        mine = sharding.take_blocks(full, world, rank, block).clone()      # stands for this rank's test() output
+        assert mine.shape[0] == sharding.local_count(n, world, rank, block)
+        got = sharding.gather_blocks(mine, n, world, rank, dst=0, block=block)
+        if rank == 0:
+            ok = ok and bool(torch.equal(got, full))
     parts = sharding.shard_clusters([5.0, 1.0, 9.0, 3.0, 3.0, 2.0, 8.0], world)
     ok = ok and sorted(sum(parts, [])) == list(range(7))
     out.put((rank, ok, (lo, hi)))
     dist.destroy_process_group()
 
 
-def test_slab_gather_world2_gloo():
+@pytest.mark.parametrize("world", [2, 3])
+def test_query_cut_and_gather_gloo(world):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 500)
-    ps = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 500) + world
+    ps = [ctx.Process(target=_gloo_worker, args=(r, world, port, q)) for r in range(world)]
     for p in ps:
         p.start()
     res = sorted(q.get(timeout=120) for _ in ps)
     for p in ps:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
-    assert res[0][2] == (0, 501) and res[1][2] == (501, 1003)
+    if world == 2:
+        assert res[0][2] == (0, 501) and res[1][2] == (501, 1003)
+
+
+def test_block_cyclic_cut_covers_every_query_once_and_balances_z():
+    from gpismap_amd import sharding
+    n = 256 ** 3
+    seen = np.zeros(n // 65536, dtype=np.int32)
+    for r in range(8):
+        for lo, hi in sharding.cyclic_blocks(n, 8, r):
+            assert hi - lo == 65536
+            seen[lo // 65536] += 1
+    assert np.all(seen == 1)
+    # one 64 K block = one x-y sheet of the 256^3 grid: every rank gets every 8th z level
+    assert [lo // 65536 for lo, _ in sharding.cyclic_blocks(n, 8, 3)][:3] == [3, 11, 19]
+    assert sharding.local_count(1003, 4, 3, 100) == 200 and sharding.local_count(1003, 4, 2, 100) == 203
+    # LPT partition: deterministic, balanced
+    costs = [float(k) ** 3 for k in (936, 900, 850, 800, 790, 700, 650, 640, 600, 500, 400, 300, 200, 120)]
+    parts = sharding.shard_clusters(costs, 4)
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 4) < 1.25 and parts == sharding.shard_clusters(costs, 4)
 
 
 def _build_dropin(tmp_path):
