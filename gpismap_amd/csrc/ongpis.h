@@ -134,15 +134,19 @@ struct EvalArgs {
     int nslot;               // chunks in the LDS ring (2 or 3)
     unsigned long long* trace;   // instrumented builds only (tools/k4_ablate.sh); nullptr otherwise
 };
-// K4 size classes by nbx = ld / 32 = ceil((K+1)/32) block rows: W = 1, 2, 4, 8 wavefronts per workgroup for
-// nbx <= 4, 8, 16, more (no upper limit: large clusters run several row groups).
-#define ONGPIS_NCLASS 4
+// K4 size classes by nbx = ld / 32 = ceil((K+1)/32) block rows: W = 1, 2, 4 wavefronts per workgroup for nbx <= 4, 8, 16
+// and 8 above (no upper limit: large clusters run several row groups).  The widest class is cut in three by size
+// (nbx <= 32, <= 48, more) only because the LDS of a launch is sized by its largest cluster: one giant cluster must not
+// push the exp table of every other cluster out of LDS.
+#define ONGPIS_NCLASS 6
 #ifndef K4_QS
 #define K4_QS 1   // measured on the 256^3 bench: 1 set / 128 VGPRs / 2 workgroups per CU 811 ms, 2 sets / 256 VGPRs / 1 per CU 870 ms
 #endif
 #define ONGPIS_TILE_Q (8 * K4_QS)   // queries per K4 workgroup (K4_QS sets of 8 sharing every X tile)
 #define ONGPIS_MAX_K 16384   // allocation sanity bound only (10 K^2 bytes per model)
-__host__ __device__ inline int ongpis_class_of_nbx(int nbx) { return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= 16 ? 2 : 3)); }
+__host__ __device__ inline int ongpis_class_of_nbx(int nbx) {
+    return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= 16 ? 2 : (nbx <= 32 ? 3 : (nbx <= 48 ? 4 : 5))));
+}
 int ongpis_eval_class(int nbx);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 #ifndef K4_NBW
 #define K4_NBW 4
 #endif
-static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, K4_W3};
+static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, K4_W3, K4_W3, K4_W3};
 constexpr int kQS = ONGPIS_TILE_Q / 8;
 constexpr int kWavesPerCU = 4 * K4_MINW;   // resident wavefronts per CU the register budget of the kernels admits
 
@@ -392,17 +392,20 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     args.nslot = nslot;
     const size_t lds = fixed + (size_t)nslot * cb * blk;
     typedef void (*kern_t)(EvalArgs);
-    static const kern_t kern[2][ONGPIS_NCLASS] = {
+    static const kern_t kern[2][4] = {
         {ongpis_eval_kernel<1, false, kQS, K4_NBW>, ongpis_eval_kernel<2, false, kQS, K4_NBW>, ongpis_eval_kernel<4, false, kQS, K4_NBW>,
          ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW>},
         {ongpis_eval_kernel<1, true, kQS, K4_NBW>, ongpis_eval_kernel<2, true, kQS, K4_NBW>, ongpis_eval_kernel<4, true, kQS, K4_NBW>,
          ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW>}};
+    const int kidx = wclass < 3 ? wclass : 3;
     static bool attr_set = false;
     if (!attr_set) {
         attr_set = true;
         for (int t = 0; t < 2; ++t)
-            for (int i = 0; i < ONGPIS_NCLASS; ++i)
-                (void)hipFuncSetAttribute((const void*)kern[t][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            for (int i = 0; i < 4; ++i) {
+                const hipError_t e = hipFuncSetAttribute((const void*)kern[t][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                if (e != hipSuccess) fprintf(stderr, "[gpismap_amd] K4 kernel %d/%d: hipFuncSetAttribute: %s\n", t, i, hipGetErrorString(e));
+            }
     }
 #if K4X & 64
     static unsigned long long* d_trace = nullptr;
@@ -410,7 +413,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 64 * 64, s);
     args.trace = d_trace;
 #endif
-    hipLaunchKernelGGL(kern[use_table][wclass], dim3(ntiles), dim3(64 * W), lds, s, args);
+    hipLaunchKernelGGL(kern[use_table][kidx], dim3(ntiles), dim3(64 * W), lds, s, args);
 #if K4X & 64
     {
         (void)hipStreamSynchronize(s);
@@ -430,7 +433,13 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
         }
     }
 #endif
-    return hipGetLastError() == hipSuccess ? GPIS_OK : GPIS_ERR_HIP;
+    const hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+        fprintf(stderr, "[gpismap_amd] K4 launch failed: %s (class %d, %d waves, %d tiles, LDS %zu B, cb %d, slots %d, table %d)\n",
+                hipGetErrorString(le), wclass, W, ntiles, lds, cb, nslot, use_table);
+        return GPIS_ERR_HIP;
+    }
+    return GPIS_OK;
 }
 
 int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }

@@ -11,27 +11,13 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 import gpismap_amd  # noqa: E402
 from test_gpu_ongpis import soa9  # noqa: E402
-
-
-def make_stress_fast(ncl, rng):
-    side = int(np.ceil(np.sqrt(ncl)))
-    c = np.arange(ncl)
-    cx = (c % side) * 0.05 + 0.025; cy = (c // side) * 0.05 + 0.025
-    gx, gy = np.meshgrid(np.arange(8), np.arange(8), indexing="ij")
-    px = cx[:, None] - 0.025 + (gx.ravel()[None, :] + 0.5) * 0.00625 + rng.uniform(-0.001, 0.001, (ncl, 64))
-    py = cy[:, None] - 0.025 + (gy.ravel()[None, :] + 0.5) * 0.00625 + rng.uniform(-0.001, 0.001, (ncl, 64))
-    pz = rng.uniform(-0.02, 0.02, (ncl, 64))
-    pos = np.stack([px, py, pz], axis=2).reshape(-1, 3).astype(np.float32)
-    n = np.array([0.0, 0.0, 1.0]) + rng.normal(0, 0.05, (ncl * 64, 3))
-    n /= np.linalg.norm(n, axis=1, keepdims=True)
-    val = np.full(ncl * 64, -0.2, dtype=np.float32)
-    return pos, n.astype(np.float32), val, rng.uniform(1e-3, 5e-3, ncl * 64).astype(np.float32), rng.uniform(0.01, 0.1, ncl * 64).astype(np.float32)
+import replay  # noqa: E402
 
 
 def main():
     ncl = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
     rng = np.random.default_rng(355)
-    pos, grad, val, sx, sg = make_stress_fast(ncl, rng)
+    pos, grad, val, sx, sg = replay.stress_clusters(ncl, rng)
     off = (np.arange(ncl + 1) * 64).astype(np.int32)
     ids = np.arange(ncl * 64, dtype=np.int32)
     st = gpismap_amd.OnGPIS(3, 0.04)
@@ -43,7 +29,7 @@ def main():
     print("train: %d clusters K=%d: device %.1f ms (%.2f us/cluster, %.2f TFLOP/s of K^3/3+2K^2), wall incl. allocation %.0f ms"
           % (ncl, K, tr, 1e3 * tr / ncl, ncl * (K ** 3 / 3 + 2 * K * K) / tr / 1e9, wall))
     nq = 64
-    xq = (pos.reshape(ncl, 64, 3)[:, rng.integers(0, 64, nq), :] + rng.normal(0, 0.005, (ncl, nq, 3))).reshape(-1, 3).astype(np.float32)
+    xq = replay.stress_queries(pos, ncl, nq, rng)
     jq = np.arange(ncl * nq, dtype=np.int32)
     jm = np.repeat(models, nq).astype(np.int32)
     out = st.eval(xq, jq, jm)
