@@ -104,10 +104,11 @@ private:
     int* d_ids_ = nullptr; int cap_ids_ = 0;
     int* d_jobs_ = nullptr; int cap_jobs_ = 0;   // train job table (4 ints per job)
     int* d_work_ = nullptr; int cap_work_ = 0;   // K3b work list (job, block column)
+    int* d_cwork_ = nullptr; int cap_cwork_ = 0; // cooperative K3: (job, g, G) per workgroup, then 2 sync ints per job
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
-    hipStream_t s2_ = nullptr;                   // side stream: small factorisations run beside the large ones
-    hipEvent_t evf_ = nullptr, evj_ = nullptr;   // fork / join
+    hipStream_t s2_ = nullptr, s3_ = nullptr;    // side streams: the three size groups of a training batch run beside each other
+    hipEvent_t evf_ = nullptr, evj_ = nullptr, evj3_ = nullptr;   // fork / joins
 };
 
 // kernels (ongpis_train.hip / ongpis_test.hip)
@@ -117,8 +118,10 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
+// K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup, sync = 2 ints per job (zeroed)
+void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, hipStream_t s);
 // K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nwork, hipStream_t s);
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nshort, hipStream_t s);
 
 struct EvalArgs {
     const ClusterModel* models;

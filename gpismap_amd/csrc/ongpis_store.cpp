@@ -14,12 +14,14 @@ OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_
 
 OnGPISStore::~OnGPISStore() {
     clear();
-    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_ej_);
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (evf_) (void)hipEventDestroy(evf_);
     if (evj_) (void)hipEventDestroy(evj_);
     if (s2_) (void)hipStreamDestroy(s2_);
+    if (s3_) (void)hipStreamDestroy(s3_);
+    if (evj3_) (void)hipEventDestroy(evj3_);
     pool_destroy(pool_);
 }
 
@@ -196,17 +198,60 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         last_train_bytes += 36.0 * N + 4.0 * (K * (K + 1) / 2.0 + K);
         last_train_maxK = std::max(last_train_maxK, (int)K);
     }
-    // K3b work list: one wavefront per (job, block column), big clusters and long columns first
-    std::vector<int> work;
-    for (int j = 0; j < nj; ++j) {
+    // Three size groups, each a chain "factorise -> invert" on its own stream so that the chains overlap:
+    //   group 0: the largest clusters, several cooperating workgroups each (jobs [0, ncoop))
+    //   group 1: one 8-wave workgroup per cluster (jobs [ncoop, n0))
+    //   group 2: K <= 256, one wavefront per cluster (jobs [n0, nj))
+    int n0 = 0;
+    while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
+    // cooperative group: G workgroups ~ nb^2 (work nb^3 over a critical path of nb steps), one workgroup per CU, at most
+    // kCoopMaxWG in the launch so that all of them are resident at once
+    constexpr int kCoopMinNb = 24, kCoopMaxWG = 240;
+    int ncoop = 0;
+    std::vector<int> cwork;
+    for (int j = 0; j < n0; ++j) {
         const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
-        for (int c = 0; c < nbj; ++c) { work.push_back(j); work.push_back(c); }
+        if (nbj < kCoopMinNb) break;
+        const int G = std::min(16, std::max(2, (nbj * nbj + 150) / 300));
+        if ((int)cwork.size() / 3 + G > kCoopMaxWG) break;
+        for (int g = 0; g < G; ++g) { cwork.push_back(j); cwork.push_back(g); cwork.push_back(G); }
+        ncoop = j + 1;
+    }
+    // K3b work lists per group: one entry per (job, block column); columns longer than kLongCol rows first (a workgroup
+    // of 8 pipelined wavefronts each), the rest one wavefront per column
+    constexpr int kLongCol = 24;
+    const int gbeg[4] = {0, ncoop, n0, nj};
+    std::vector<int> work;
+    int wl_off[3], wl_long[3], wl_short[3];
+    for (int grp = 0; grp < 3; ++grp) {
+        std::vector<int> wlong, wshort;
+        for (int j = gbeg[grp]; j < gbeg[grp + 1]; ++j) {
+            const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+            for (int c = 0; c < nbj; ++c) {
+                std::vector<int>& w = (nbj - c > kLongCol) ? wlong : wshort;
+                w.push_back(j); w.push_back(c);
+            }
+        }
+        wl_off[grp] = (int)work.size(); wl_long[grp] = (int)wlong.size() / 2; wl_short[grp] = (int)wshort.size() / 2;
+        work.insert(work.end(), wlong.begin(), wlong.end());
+        work.insert(work.end(), wshort.begin(), wshort.end());
     }
     if ((int)work.size() > cap_work_) {
         (void)hipFree(d_work_); d_work_ = nullptr;
         int cap = (int)work.size() * 3 / 2 + 1024;
         GPIS_HIP(hipMalloc(&d_work_, sizeof(int) * (size_t)cap));
         cap_work_ = cap;
+    }
+    if (ncoop > 0) {
+        const size_t need = cwork.size() + 2 * (size_t)ncoop;
+        if ((int)need > cap_cwork_) {
+            (void)hipFree(d_cwork_); d_cwork_ = nullptr;
+            int cap = (int)need * 2 + 1024;
+            GPIS_HIP(hipMalloc(&d_cwork_, sizeof(int) * (size_t)cap));
+            cap_cwork_ = cap;
+        }
+        GPIS_HIP(hipMemcpyAsync(d_cwork_, cwork.data(), sizeof(int) * cwork.size(), hipMemcpyHostToDevice, s));
+        GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * 2 * (size_t)ncoop, s));
     }
     GPIS_HIP(hipMemcpyAsync(d_ids_, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
@@ -217,29 +262,27 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     }
     ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
     ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
-    // Factorisation (also produces the re-tiled copy Lt).  The table is sorted by size; the small clusters (K <= 256)
-    // get single-wave workgroups (ongpis_launch_chol), on a side stream beside the wide ones.
-    int n0 = 0;
-    while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
-    const bool fork = n0 > 0 && n0 < nj;
-    hipStream_t sn = s;
-    if (fork) {
-        if (!s2_) {
-            GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
-            GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
-            GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
-        }
-        GPIS_HIP(hipEventRecord(evf_, s));
-        GPIS_HIP(hipStreamWaitEvent(s2_, evf_, 0));
-        sn = s2_;
+    // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream
+    if (!s2_) {
+        GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+        GPIS_HIP(hipStreamCreateWithFlags(&s3_, hipStreamNonBlocking));
+        GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
+        GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
+        GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
     }
-    if (n0 > 0) ongpis_launch_chol(d_models_, d_jobs_, n0, 0, s);
-    if (nj > n0) ongpis_launch_chol(d_models_, d_jobs_ + 4 * n0, nj - n0, 1, sn);
-    if (fork) {
-        GPIS_HIP(hipEventRecord(evj_, s2_));
-        GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
+    GPIS_HIP(hipEventRecord(evf_, s));
+    hipStream_t gs[3] = {s, s3_, s2_};
+    for (int grp = 0; grp < 3; ++grp) {
+        const int nbeg = gbeg[grp], ncnt = gbeg[grp + 1] - gbeg[grp];
+        if (ncnt <= 0) continue;
+        if (grp > 0) GPIS_HIP(hipStreamWaitEvent(gs[grp], evf_, 0));
+        if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), gs[0]);
+        else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
+        // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
+        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_short[grp], gs[grp]);
+        if (grp == 1) { GPIS_HIP(hipEventRecord(evj3_, s3_)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
+        if (grp == 2) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     }
-    ongpis_launch_inverse(d_models_, d_jobs_, d_work_, (int)work.size() / 2, s);   // K3b: X = L^-1, re-tiled for K4
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));

@@ -166,6 +166,60 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 + c; }
 
+// z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2); finally the padding the blocked solves rely on.
+template <int NTH>
+__device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* D, float* av, int tid, int lane, int wave) {
+    const int K = m.K, ld = m.ld, nb = m.nb;
+    float* L = m.L;
+    for (int jj = tid; jj < K; jj += NTH) m.y[jj] = L[K + (size_t)jj * ld];
+    __syncthreads();
+    for (int c = nb - 1; c >= 0; --c) {
+        const int cr = 32 * c;
+        if (wave == 0) {
+            if (lane < 32)
+                for (int cc = 0; cc < 32; ++cc) D[lane * 33 + cc] = L[(cr + lane) + (size_t)(cr + cc) * ld];
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_wave_barrier();
+            volatile float* Dv = D;
+            float b = (lane < 32 && cr + lane < K) ? m.y[cr + lane] : 0.f;
+            for (int k = 31; k >= 0; --k) {
+                if (cr + k >= K) continue;
+                float t = b / Dv[(lane & 31) * 33 + (lane & 31)];
+                float ak = __shfl(t, k);
+                if (lane == k) b = ak;
+                if (lane < k) b = fmaf(-Dv[k * 33 + lane], ak, b);
+            }
+            if (lane < 32) {
+                av[lane] = (cr + lane < K) ? b : 0.f;
+                if (cr + lane < K) m.alpha[cr + lane] = b;
+            }
+        }
+        __syncthreads();
+        for (int jj = tid; jj < cr; jj += NTH) {
+            float s = m.y[jj];
+            const float* col = L + (size_t)cr + (size_t)jj * ld;
+            for (int k = 31; k >= 0; --k)
+                if (cr + k < K) s = fmaf(-col[k], av[k], s);
+            m.y[jj] = s;
+        }
+        __syncthreads();
+    }
+    // restore the identity in row K so the padded square is a valid triangular factor
+    for (int jj = tid; jj < K; jj += NTH) L[K + (size_t)jj * ld] = 0.f;
+    if (tid == 0) L[K + (size_t)K * ld] = 1.f;
+    // K4 runs over whole 32-row blocks without row predicates: the padding rows K..32nb-1 must stay exactly
+    // zero through its solve, so alpha is zero there and row K (the y row) is cleared in the re-tiled copy too.
+    for (int jj = K + tid; jj < ld; jj += NTH) m.alpha[jj] = 0.f;
+    if (K % 32 != 0) {
+        const int pr = K - 32 * (nb - 1);
+        for (int idx = tid; idx < (nb - 1) * 8; idx += NTH) {
+            const int c = idx >> 3, g = (idx >> 1) & 3, hh = idx & 1;
+            float4* t = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(nb - 1, c) * 1024);
+            t[g * 64 + hh * 32 + pr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 template <int NT, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
                                                               const int* __restrict__ d_jobs) {
@@ -364,56 +418,228 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
         __syncthreads();   // column j complete: Lt tiles visible, Lc reusable
     }
 
-    // z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2)
-    for (int jj = tid; jj < K; jj += 64 * NW) m.y[jj] = L[K + (size_t)jj * ld];
-    __syncthreads();
-    for (int c = nb - 1; c >= 0; --c) {
-        const int cr = 32 * c;
-        if (wave == 0) {
-            if (lane < 32)
-                for (int cc = 0; cc < 32; ++cc) D[lane * 33 + cc] = L[(cr + lane) + (size_t)(cr + cc) * ld];
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            volatile float* Dv = D;
-            float b = (lane < 32 && cr + lane < K) ? m.y[cr + lane] : 0.f;
-            for (int k = 31; k >= 0; --k) {
-                if (cr + k >= K) continue;
-                float t = b / Dv[(lane & 31) * 33 + (lane & 31)];
-                float ak = __shfl(t, k);
-                if (lane == k) b = ak;
-                if (lane < k) b = fmaf(-Dv[k * 33 + lane], ak, b);
-            }
-            if (lane < 32) {
-                av[lane] = (cr + lane < K) ? b : 0.f;
-                if (cr + lane < K) m.alpha[cr + lane] = b;
-            }
-        }
-        __syncthreads();
-        for (int jj = tid; jj < cr; jj += 64 * NW) {
-            float s = m.y[jj];
-            const float* col = L + (size_t)cr + (size_t)jj * ld;
-            for (int k = 31; k >= 0; --k)
-                if (cr + k < K) s = fmaf(-col[k], av[k], s);
-            m.y[jj] = s;
-        }
-        __syncthreads();
-    }
-    // restore the identity in row K so the padded square is a valid triangular factor
-    for (int jj = tid; jj < K; jj += 64 * NW) L[K + (size_t)jj * ld] = 0.f;
-    if (tid == 0) L[K + (size_t)K * ld] = 1.f;
-    // K4 runs over whole 32-row blocks without row predicates: the padding rows K..32nb-1 must stay exactly
-    // zero through its solve, so alpha is zero there and row K (the y row) is cleared in the re-tiled copy too.
-    for (int jj = K + tid; jj < ld; jj += 64 * NW) m.alpha[jj] = 0.f;
-    if (K % 32 != 0) {
-        const int pr = K - 32 * (nb - 1);
-        for (int idx = tid; idx < (nb - 1) * 8; idx += 64 * NW) {
-            const int c = idx >> 3, g = (idx >> 1) & 3, hh = idx & 1;
-            float4* t = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(nb - 1, c) * 1024);
-            t[g * 64 + hh * 32 + pr] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    }
+    chol_epilogue<64 * NW>(m, D, av, tid, lane, wave);
 }
 
+
+// ---------------------------------------------------------------------------
+// K3 for the LARGEST clusters: G cooperating workgroups per cluster (one per CU).  A single workgroup needs ~15 ms for a
+// K = 2300 factorisation (74 dependent block columns on one CU) while the rest of the chip idles.  Here block ROW bi of
+// the factor belongs to workgroup bi mod G, the sweep is still left-looking and every element keeps its ascending-(p, k)
+// fmaf chain (bit-identical to the single-workgroup kernel):
+//   step j, owner of row j:   the diagonal block L(j,j) is already fully accumulated (see below) -> factor it in registers,
+//                             write L_jj and its inverse, publish "row j ready" (release fence + device-scope flag);
+//   step j, every workgroup:  acquire row j, then for each owned row bi > j (dealt to the 8 wavefronts)
+//                                 T = A(bi,j) - sum_{p<j} L(bi,p) L(j,p)^T     own row (local) x row j (remote, just acquired)
+//                                 L(bi,j) = T L_jj^-T ; store column-major + re-tiled
+//                                 A(bi,bi) -= L(bi,j) L(bi,j)^T                 incremental diagonal: when step bi arrives the
+//                                                                               diagonal block only needs the factorisation
+// One flag hand-over per block column (row j's owner -> everybody); visibility follows the gfx950 recipe (plain stores,
+// workgroup barrier, one lane: agent-scope release + vmcnt(0) + relaxed device-scope flag store; consumer: one lane polls,
+// agent-scope acquire, workgroup barrier, plain loads of tiles nobody on this CU has touched before).  The launch holds
+// at most one workgroup per CU (<= 240 in total), so every workgroup of a cluster becomes resident and the waits end.
+// The blocked back-substitution for alpha runs on workgroup 0 of the cluster after all rows are done.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterModel* __restrict__ models,
+                                                                const int* __restrict__ d_jobs, const int* __restrict__ cwork,
+                                                                int* __restrict__ sync) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float D[32 * 33];
+    __shared__ __attribute__((aligned(16))) float Lc[32 * 32];
+    __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
+    __shared__ float av[32];
+    const int job = cwork[3 * blockIdx.x], g = cwork[3 * blockIdx.x + 1], G = cwork[3 * blockIdx.x + 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const ClusterModel m = models[JOB_MODEL(job)];
+    const int K = m.K, ld = m.ld, nb = m.nb;
+    float* L = m.L;
+    const int nbr = ld / 32;
+    const int ntl = nbr * (nbr + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const int Tvoff = lane * 16;
+    int* rowready = sync + 2 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially)
+    int* alldone = sync + 2 * job + 1;   // workgroups that have finished their rows
+    auto load_tile = [&](float (&o)[16], int b, int c) {
+        const int sbase = tri_index(b, c) * 4096;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + gg * 1024, 0);
+            o[4 * gg + 0] = __uint_as_float(q[0]); o[4 * gg + 1] = __uint_as_float(q[1]);
+            o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
+        }
+    };
+    auto wait_flag = [&](int* f, int v) {     // one lane polls a device-scope flag, then the workgroup acquires
+        if (tid == 0) {
+            long spins = 0;
+            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v && ++spins < (1L << 28)) __builtin_amdgcn_s_sleep(8);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    };
+
+    for (int j = 0; j < nb; ++j) {
+        const int pw = min(32, K - 32 * j);
+        // ---- row j's owner: factor the accumulated diagonal block, publish the row
+        if (j % G == g) {
+            __syncthreads();           // this workgroup's stores of the previous steps (tiles of row j, its diagonal updates)
+            if (wave == 0) {
+                // (device-scope loads: the block was modified by other wavefronts of this CU after it was last read here, and
+                // the vector L1 is not refreshed by stores)
+                float* Cb = L + (size_t)(j * 32 + l31) + (size_t)(j * 32) * ld;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    D[l31 * 33 + rowmap_t(r, h)] = __hip_atomic_load(Cb + (size_t)rowmap_t(r, h) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (pw == 32) {
+                    const int row = lane & 31;
+                    float a[32];
+#pragma unroll
+                    for (int k = 0; k < 32; ++k) a[k] = D[row * 33 + k];
+#pragma unroll
+                    for (int c = 0; c < 32; ++c) {
+                        const float piv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), c));
+                        const float d = sqrtf(piv);
+                        const float lic = a[c] / d;
+                        a[c] = (row == c) ? d : lic;
+                        const float nl = -lic;
+#pragma unroll
+                        for (int k = c + 1; k < 32; ++k) {
+                            const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), k));
+                            a[k] = fmaf(nl, lkc, a[k]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (lane < 32) {
+#pragma unroll
+                        for (int c = 0; c < 32; ++c) {
+                            Lc[c * 32 + lane] = a[c];
+                            if (c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = a[c];
+                        }
+                    }
+                } else {
+                    volatile float* Dv = D;
+                    for (int c = 0; c < pw; ++c) {
+                        float d = sqrtf(Dv[c * 33 + c]);
+                        float lij = 0.f;
+                        const bool below = (lane > c && lane < 32);
+                        if (below) lij = Dv[lane * 33 + c] / d;
+                        if (lane == c) Dv[c * 33 + c] = d;
+                        if (below) Dv[lane * 33 + c] = lij;
+                        if (below) {
+                            const float nl = -lij;
+                            const int kend = min(lane, pw - 1);
+                            for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 32) {
+                        for (int c = 0; c < 32; ++c) {
+                            float v = Dv[lane * 33 + c];
+                            Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
+                            if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it)
+                f32x16 x;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
+                diag_solve32<true>(x, Lc, h);
+                float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
+            }
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(rowready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        // ---- everybody: acquire row j, then the owned rows below it
+        const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
+        if (first >= nbr) continue;                                   // nothing left for this workgroup in later columns either
+        wait_flag(rowready, j + 1);
+        if (j % G != g) {     // non-owners rebuild the padded diagonal factor from the published block
+            for (int idx = tid; idx < 1024; idx += 512) {
+                const int c = idx >> 5, r = idx & 31;
+                const float v = L[(size_t)(j * 32 + r) + (size_t)(j * 32 + c) * ld];
+                Lc[c * 32 + r] = (pw == 32 || (r < pw && c < pw)) ? v : (r == c ? 1.f : 0.f);
+            }
+        }
+        __syncthreads();
+        for (int bi = first + wave * G; bi < nbr; bi += NW * G) {
+            f32x16 acc;
+            {
+                const float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = Cb[(size_t)rowmap_t(r, h) * ld];
+            }
+            if (j > 0) {
+                float a_[2][16], bq[2][16];
+                load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
+#pragma unroll 1
+                for (int p = 0; p < j; p += 2) {
+                    if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(bq[1], bi, p + 1); }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[0][kk], acc, 0, 0, 0);
+                    if (p + 1 < j) {
+                        if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(bq[0], bi, p + 2); }
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[1][kk], acc, 0, 0, 0);
+                    }
+                }
+            }
+            diag_solve32<true>(acc, Lc, h);
+            float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Cb[(size_t)rowmap_t(r, h) * ld] = acc[r];
+            float* T = Tt[wave];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float tq[16];      // -L(bi, j) in A-operand order
+            float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                float4 q;
+                q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
+                q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
+                q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
+                q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
+                dst[gg * 64 + lane] = q;
+                tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (bi < nb) {     // incremental diagonal of row bi: A(bi,bi) -= L(bi,j) L(bi,j)^T (rows without a pivot have none)
+                float* Db = L + (size_t)(bi * 32 + l31) + (size_t)(bi * 32) * ld;
+                f32x16 dacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[r] = __hip_atomic_load(Db + (size_t)rowmap_t(r, h) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Db[(size_t)rowmap_t(r, h) * ld] = dacc[r];
+            }
+        }
+    }
+    // ---- all rows done: workgroup 0 runs the back-substitution over the complete factor
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(alldone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (g != 0) return;
+    wait_flag(alldone, G);
+    chol_epilogue<512>(m, D, av, tid, lane, wave);
+}
 
 // ---------------------------------------------------------------------------
 // K3b: explicit inverse X = L^-1 of a trained factor, re-tiled for K4.  grid = (job, block column) pairs,
@@ -428,10 +654,20 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
 // K4 and as Zt(b, c) = (X_bc)^T for this wave's own later rows.  Row K of X is replaced by alpha (K4 reads the mean
 // off row K of V = X k*).  A cluster of nb block rows is nb independent wavefronts; a batch of clusters fills the chip.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
-                                                         const int* __restrict__ d_jobs, const int* __restrict__ work) {
-    __shared__ __attribute__((aligned(16))) float T[32 * 36];
+// NWI = 1: one wavefront per block column.  NWI = 8 (long columns of large clusters): the rows of the column are dealt to
+// the 8 wavefronts of a workgroup round-robin; row b still needs every earlier row of the column, so the wavefronts run as
+// a software pipeline -- each accumulates its row over the rows already published (LDS counter `rowdone`, tiles travel
+// through Zt in L2) and waits only for the last few.  The chain of a row is unchanged (ascending p, k): same bits.
+template <int NWI>
+__global__ __launch_bounds__(64 * NWI) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
+                                                               const int* __restrict__ d_jobs, const int* __restrict__ work) {
+    __shared__ __attribute__((aligned(16))) float Tall[NWI][32 * 36];
+    __shared__ int rowdone_s;
+    typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;
+    lds_flag_ptr rowdone = (lds_flag_ptr)&rowdone_s;
     const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* T = Tall[wave];
     const int job = work[2 * blockIdx.x], c = work[2 * blockIdx.x + 1];
     const ClusterModel m = models[JOB_MODEL(job)];
     const int K = m.K, nb = m.nb, nbx = m.ld / 32;
@@ -439,6 +675,10 @@ __global__ __launch_bounds__(64) void ongpis_inv_kernel(const ClusterModel* __re
     const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
+    if (NWI > 1) {
+        if (threadIdx.x == 0) *rowdone = c - 1;
+        __syncthreads();
+    }
     auto load_tile = [&](float (&o)[16], const __amdgpu_buffer_rsrc_t& rs, int b, int cc) {
         const int sbase = tri_index(b, cc) * 4096;
 #pragma unroll
@@ -476,6 +716,14 @@ __global__ __launch_bounds__(64) void ongpis_inv_kernel(const ClusterModel* __re
         }
         __builtin_amdgcn_wave_barrier();
     };
+    // publish row b of the column: the tile stores have reached L2 before the counter moves
+    auto publish = [&](int b) {
+        if (NWI > 1) {
+            __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) *rowdone = b;
+        }
+    };
     auto times_inverse = [&](const f32x16& sacc, int b) {   // inv(L_bb) * S, S = accumulator tile as the B operand
         float ai[16];
         load_tile(ai, Lrs, b, b);
@@ -486,35 +734,48 @@ __global__ __launch_bounds__(64) void ongpis_inv_kernel(const ClusterModel* __re
         for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], sacc[kk], v, 0, 0, 0);
         return v;
     };
-    {   // diagonal tile: inv(L_cc) times the identity
+    if (wave == 0) {   // diagonal tile: inv(L_cc) times the identity
         f32x16 e;
 #pragma unroll
         for (int r = 0; r < 16; ++r) e[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
         emit(times_inverse(e, c), c);
+        publish(c);
     }
-    for (int b = c + 1; b < nb; ++b) {
-        __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): this wave's Zt stores are complete before it reads them back
+    for (int b = c + 1 + wave; b < nb; b += NWI) {
+        if (NWI == 1) __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): this wave's Zt stores are complete before it reads them back
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-        float av[2][16], zb[2][16];
-        load_tile(av[0], Lrs, b, c);
-        load_tile(zb[0], Zrs, c, c);
-#pragma unroll 1
-        for (int p = c; p < b; p += 2) {
-            if (p + 1 < b) { load_tile(av[1], Lrs, b, p + 1); load_tile(zb[1], Zrs, p + 1, c); }
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk], zb[0][kk], sacc, 0, 0, 0);
-            if (p + 1 < b) {
-                if (p + 2 < b) { load_tile(av[0], Lrs, b, p + 2); load_tile(zb[0], Zrs, p + 2, c); }
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk], zb[1][kk], sacc, 0, 0, 0);
+        int p = c;
+        while (p < b) {
+            int pe = b - 1;                 // last row usable now
+            if (NWI > 1) {
+                int avail = *rowdone;
+                while (avail < p) { __builtin_amdgcn_s_sleep(1); avail = *rowdone; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                pe = min(avail, b - 1);
             }
+            float av[2][16], zb[2][16];
+            load_tile(av[0], Lrs, b, p);
+            load_tile(zb[0], Zrs, p, c);
+#pragma unroll 1
+            for (int q = p; q <= pe; q += 2) {
+                if (q + 1 <= pe) { load_tile(av[1], Lrs, b, q + 1); load_tile(zb[1], Zrs, q + 1, c); }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk], zb[0][kk], sacc, 0, 0, 0);
+                if (q + 1 <= pe) {
+                    if (q + 2 <= pe) { load_tile(av[0], Lrs, b, q + 2); load_tile(zb[0], Zrs, q + 2, c); }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk], zb[1][kk], sacc, 0, 0, 0);
+                }
+            }
+            p = pe + 1;
         }
         emit(times_inverse(sacc, b), b);
+        publish(b);
     }
     // K a multiple of 32: row K sits alone in an extra block row (nb = nbx - 1) whose tiles hold only alpha
-    if (nbx > nb) {
+    if (nbx > nb && wave == 0) {
         f32x16 z;
 #pragma unroll
         for (int r = 0; r < 16; ++r) z[r] = 0.f;
@@ -536,8 +797,14 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nwork, hipStream_t s) {
-    if (nwork > 0) hipLaunchKernelGGL(ongpis_inv_kernel, dim3(nwork), dim3(64), 0, s, d_models, d_jobs, d_work);
+void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, hipStream_t s) {
+    if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync);
+}
+
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nshort, hipStream_t s) {
+    // the work list starts with the long columns (8 cooperating wavefronts each), the rest take one wavefront per column
+    if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work);
+    if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1>), dim3(nshort), dim3(64), 0, s, d_models, d_jobs, d_work + 2 * nlong);
 }
 
 }  // namespace gpis
