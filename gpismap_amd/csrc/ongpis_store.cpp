@@ -206,7 +206,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
     // cooperative group: G workgroups ~ nb^2 (work nb^3 over a critical path of nb steps), one workgroup per CU, at most
     // kCoopMaxWG in the launch so that all of them are resident at once
-    constexpr int kCoopMinNb = 24, kCoopMaxWG = 240;
+    constexpr int kCoopMinNb = 40, kCoopMaxWG = 240;   // below ~40 block rows one workgroup per cluster is faster (measured)
     int ncoop = 0;
     std::vector<int> cwork;
     for (int j = 0; j < n0; ++j) {

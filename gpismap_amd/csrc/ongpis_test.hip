@@ -43,20 +43,33 @@ typedef const int __attribute__((address_space(1))) * giptr;
 #ifndef K4_MINW
 #define K4_MINW (K4_QS == 1 ? 4 : 2)   // wavefronts per SIMD the register budget is cut for (128 / 256 VGPRs)
 #endif
-#ifndef K4_SYNC_BARRIER
-#define K4_SYNC_BARRIER 1   // 1: one workgroup barrier per chunk; 0: per-wave ready/done flags in LDS (no barrier)
+
+// ---- build-time shape of the kernels (defaults = the measured best; tools/k4_ablate.sh overrides them) ----
+#ifndef K4_W3
+#define K4_W3 8            // wavefronts per workgroup of the widest class
+#endif
+#ifndef K4_NBW
+#define K4_NBW 4
+#endif
+#ifndef K4_AVBUF
+#define K4_AVBUF 1           // X tile buffers per wave.  2 (next tile prefetched during the current product) pushes the kernel over
+                            // 128 VGPRs: one accumulator tile then lives in scratch (2.8 TB of spill traffic per 256^3 pass) --
+                            // F = 5 bench 1379 ms/step with 2 buffers, 1233 ms/step with 1 (107 VGPRs, no scratch)
+#endif
+#ifndef K4_WP3
+#define K4_WP3 0            // generating-only wavefronts of the widest classes (0: unified).  Measured on the F = 5 bench: 2 of 8
+                            // waves generating (6 x 4 rows per group) 1497 ms/step, unified 1360 ms/step
 #endif
 
 constexpr int kTileStride = 36;                 // floats per row of a B tile in LDS (conflict-free 16-byte row writes AND operand reads)
 constexpr int kTileFloats = 32 * kTileStride;   // 1152
 
-typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;   // explicit LDS: volatile generic pointers become flat loads
-
-// W wavefronts, NBW block rows per wavefront and row group, QS query sets of 8 per workgroup (every X tile feeds QS
-// tile products)
-template <int W, bool TABLE, int QS, int NBW>
+// W wavefronts of which WP only generate B tiles (0: every wavefront generates and multiplies), NBW block rows per
+// multiplying wavefront and row group, QS query sets of 8 per workgroup (every X tile feeds QS tile products)
+template <int W, bool TABLE, int QS, int NBW, int WP>
 __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A) {
-    constexpr int RG = NBW * W;   // block rows per row group
+    constexpr int WC = W - WP;    // wavefronts that own block rows (consumers)
+    constexpr int RG = NBW * WC;  // block rows per row group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tile = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -82,12 +95,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     constexpr int ES = 8 * QS + 1;  // doubles per point in the exp table: odd stride -> conflict-free 8-byte reads across points
     float* red = reinterpret_cast<float*>(smem);                       // [W][NC] sums of squares, then [NC] means
     float4* s_xq = reinterpret_cast<float4*>(red + W * NC + NC);       // [16] the tile's query points
-    lds_flag_ptr flags = (lds_flag_ptr)(s_xq + 16);                    // rdyw[W] then donew[W]; 32 ints reserved
     int* s_ri = reinterpret_cast<int*>(s_xq + 16) + 32;                // [ld] row -> point | component
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
     double* etab = reinterpret_cast<double*>(s_x4 + N);                // [N][16] exp table (optional)
     float* Bbuf = reinterpret_cast<float*>(etab + (TABLE ? (((size_t)N * ES + 1) & ~(size_t)1) : 0));   // [NSLOT][CB][QS][32*36]
-    lds_flag_ptr rdyw = flags, donew = flags + W;
 
     const float scale = mp->scale;
     const float a = (float)(sqrt(3.0) / (double)scale);
@@ -98,7 +109,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         for (int i = tid; i < ld; i += 64 * W) s_ri[i] = g_ri[i];
         for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
         if (tid < 16) s_xq[tid] = (tid < jcnt) ? A.xq[A.job_q[joff + tid]] : make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tid < 32) flags[tid] = -1;
         __syncthreads();
     }
     K4_STAMP();
@@ -184,27 +194,24 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         else emit_rows(std::integral_constant<int, 3>(), c, qs, tbuf);
     };
 
-    // ---- dataflow between the wavefronts (no barrier in the main loop).  The B chunks of all row groups form one
-    // sequence gci = 0, 1, ...; chunk gci lives in ring slot gci % NSLOT; tile j of a chunk is made by wave j % W.
-    // rdyw[w] = last chunk whose tiles wave w has finished writing, donew[w] = last chunk wave w has finished reading.
-    auto wait_all_ge = [&](lds_flag_ptr f, int v) {
-        if (K4_SYNC_BARRIER) return;
-        while (__builtin_amdgcn_ballot_w64(lane < W && f[lane < W ? lane : 0] < v)) __builtin_amdgcn_s_sleep(1);
-    };
+    // ---- B chunks.  The chunks of all row groups form one sequence gci = 0, 1, ...; chunk gci lives in ring slot
+    // gci % NSLOT (NSLOT = 2: the chunk being multiplied and the one being generated); one workgroup barrier per chunk.
+    // WP = 0: tile j of a chunk is made by wave j % W, every wave generates AND multiplies.  WP > 0 (the widest classes):
+    // the last WP waves only generate, the first WC only multiply -- the accumulators (64 VGPRs) and the generation code
+    // (double-precision kernel entries) are then never live in the same wave, which is what keeps the kernel inside
+    // 128 VGPRs without spilling accumulator tiles to scratch, and generation never sits in a multiplying wave's
+    // instruction stream.
     const int ngroups = (nbx + RG - 1) / RG;
     auto group_cmax = [&](int g) { return min(nbx - 1 - g * RG, nb - 1); };   // last column block a row of group g multiplies with
     int pg = 0, pci = 0, pgci = 0;   // producer cursor: group, chunk in group, chunk in sequence
     auto produce_next = [&]() {
         if (pg >= ngroups) return;
         const int cmax = group_cmax(pg);
-        wait_all_ge(donew, pgci - NSLOT);     // every wave has finished reading the chunk that used this slot
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
         float* slot = Bbuf + (size_t)(pgci % NSLOT) * CB * QS * kTileFloats;
         const int c0 = pci * CB;
-        for (int j = wave; j < CB && c0 + j <= cmax; j += W)
+        const int j0 = (WP > 0) ? wave - WC : wave, jstep = (WP > 0) ? WP : W;
+        for (int j = j0; j < CB && c0 + j <= cmax; j += jstep)
             for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + j, qs, slot + (size_t)(j * QS + qs) * kTileFloats);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-        if (lane == 0) rdyw[wave] = pgci;
         ++pgci;
         if (++pci > cmax / CB) { pci = 0; ++pg; }
     };
@@ -241,75 +248,93 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 
     float ss[2] = {0.f, 0.f};         // partial sums of squares of V over this lane's rows (order O3, oracle reduce_ss)
     float mean_val[2] = {0.f, 0.f};   // row K of V (the lane that owns it)
-    const int LA = NSLOT - 1;         // chunks produced ahead of consumption
-    const bool gen_first = (W < 2) || (wave < W / 2);   // half of the waves generate before multiplying, half after
-    for (int i = 0; i < LA; ++i) produce_next();
-    if (K4_SYNC_BARRIER) __syncthreads();
-    K4_STAMP();
-    int gci = 0;
-    for (int g = 0; g < ngroups; ++g) {
-        // this wave's block rows in group g: slot t holds the (g RG + t W + q)-th largest row, q snaking with t
-        int brow[NBW];
-#pragma unroll
-        for (int t = 0; t < NBW; ++t) {
-            const int i = g * RG + t * W + ((t & 1) ? (W - 1 - wave) : wave);
-            brow[t] = nbx - 1 - i;      // < 0: no row
+    const int LA = NSLOT - 1;         // chunks generated ahead of the multiplication
+    int total_chunks = 0;
+    for (int g = 0; g < ngroups; ++g) total_chunks += group_cmax(g) / CB + 1;
+    if (WP > 0 && wave >= WC) {
+        // ---- generating wavefronts
+        for (int i = 0; i < LA; ++i) produce_next();
+        __syncthreads();
+        for (int gci = 0; gci < total_chunks; ++gci) {
+            produce_next();          // chunk gci + LA, while the others multiply chunk gci
+            __syncthreads();
         }
-        const int cmax = group_cmax(g);
-        const int nch = cmax / CB + 1;
-        f32x16 acc[NBW][QS];
+    } else {
+        // ---- multiplying wavefronts (and, with WP = 0, generating ones)
+        const bool gen_first = (W < 2) || (wave < W / 2);   // WP = 0: half of the waves generate before multiplying, half after
+        if (WP == 0) for (int i = 0; i < LA; ++i) produce_next();
+        __syncthreads();
+        K4_STAMP();
+        int gci = 0;
+        for (int g = 0; g < ngroups; ++g) {
+            // this wave's block rows in group g: slot t holds the (g RG + t WC + q)-th largest row, q snaking with t
+            int brow[NBW];
 #pragma unroll
-        for (int t = 0; t < NBW; ++t)
+            for (int t = 0; t < NBW; ++t) {
+                const int i = g * RG + t * WC + ((t & 1) ? (WC - 1 - wave) : wave);
+                brow[t] = nbx - 1 - i;      // < 0: no row
+            }
+            const int cmax = group_cmax(g);
+            const int nch = cmax / CB + 1;
+            f32x16 acc[NBW][QS];
 #pragma unroll
-            for (int q = 0; q < QS; ++q)
+            for (int t = 0; t < NBW; ++t)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
+                for (int q = 0; q < QS; ++q)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
 
-        for (int ci = 0; ci < nch; ++ci, ++gci) {
-            if (gen_first && !(K4X & 1)) produce_next();
-            wait_all_ge(rdyw, gci);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-            {
-                const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
-                const int c0 = ci * CB;
+            for (int ci = 0; ci < nch; ++ci, ++gci) {
+                if (WP == 0 && gen_first && !(K4X & 1)) produce_next();
+                {
+                    const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
+                    const int c0 = ci * CB;
 #pragma unroll
-                for (int t = 0; t < NBW; ++t) {
-                    const int b = brow[t];
-                    if (b >= c0) {
-                        const int cend = min(min(c0 + CB - 1, b), cmax);
-                        float av[2][16];
-                        load_a(av[0], b, c0);
+                    for (int t = 0; t < NBW; ++t) {
+                        const int b = brow[t];
+                        if (b >= c0) {
+                            const int cend = min(min(c0 + CB - 1, b), cmax);
+#if K4_AVBUF == 1
+                            float av1[16];
 #pragma unroll 1
-                        for (int c = c0; c <= cend; c += 2) {
-                            if (c + 1 <= cend && !(K4X & 16)) load_a(av[1], b, c + 1);
-                            mfma_tile(acc[t][0], acc[t][QS - 1], av[0], buf + (size_t)(c - c0) * QS * kTileFloats);
-                            if (c + 1 <= cend) {
-                                if (c + 2 <= cend && !(K4X & 16)) load_a(av[0], b, c + 2);
-                                mfma_tile(acc[t][0], acc[t][QS - 1], av[(K4X & 16) ? 0 : 1], buf + (size_t)(c + 1 - c0) * QS * kTileFloats);
+                            for (int c = c0; c <= cend; ++c) {
+                                load_a(av1, b, c);
+                                mfma_tile(acc[t][0], acc[t][QS - 1], av1, buf + (size_t)(c - c0) * QS * kTileFloats);
                             }
+#else
+                            float av[2][16];
+                            load_a(av[0], b, c0);
+#pragma unroll 1
+                            for (int c = c0; c <= cend; c += 2) {
+                                if (c + 1 <= cend && !(K4X & 16)) load_a(av[1], b, c + 1);
+                                mfma_tile(acc[t][0], acc[t][QS - 1], av[0], buf + (size_t)(c - c0) * QS * kTileFloats);
+                                if (c + 1 <= cend) {
+                                    if (c + 2 <= cend && !(K4X & 16)) load_a(av[0], b, c + 2);
+                                    mfma_tile(acc[t][0], acc[t][QS - 1], av[(K4X & 16) ? 0 : 1], buf + (size_t)(c + 1 - c0) * QS * kTileFloats);
+                                }
+                            }
+#endif
                         }
                     }
                 }
+                if (WP == 0 && !gen_first && !(K4X & 1)) produce_next();
+                __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-            if (lane == 0) donew[wave] = gci;
-            if (!gen_first && !(K4X & 1)) produce_next();
-            if (K4_SYNC_BARRIER) __syncthreads();   // chunk gci consumed and chunk gci + LA produced by every wave
-        }
-        // sums of squares of the finished rows; row K (block nbx-1: group 0, slot 0, wave 0) is the mean
+            // sums of squares of the finished rows; row K (block nbx-1: group 0, slot 0, wave 0) is the mean
 #pragma unroll
-        for (int t = 0; t < NBW; ++t) {
-            if (brow[t] < 0) continue;
-            const bool has_mean = (g == 0 && t == 0 && wave == 0);
-            const int kr = K & 31;
+            for (int t = 0; t < NBW; ++t) {
+                if (brow[t] < 0) continue;
+                const bool has_mean = (g == 0 && t == 0 && wave == 0);
+                const int kr = K & 31;
 #pragma unroll
-            for (int q = 0; q < QS; ++q)
+                for (int q = 0; q < QS; ++q)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[t][q][r];
-                    if (has_mean && rowmap_t(r, h) == kr) mean_val[q] = v;
-                    else ss[q] = fmaf(v, v, ss[q]);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[t][q][r];
+                        if (has_mean && rowmap_t(r, h) == kr) mean_val[q] = v;
+                        else ss[q] = fmaf(v, v, ss[q]);
+                    }
+            }
         }
     }
 
@@ -345,12 +370,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 }
 
 // Size classes by nbx = ceil((K+1)/32): W wavefronts per workgroup (ongpis.h, ongpis_class_of_nbx).
-#ifndef K4_W3
-#define K4_W3 8            // wavefronts per workgroup of the widest class
-#endif
-#ifndef K4_NBW
-#define K4_NBW 4
-#endif
 static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, K4_W3, K4_W3, K4_W3};
 constexpr int kQS = ONGPIS_TILE_Q / 8;
 constexpr int kWavesPerCU = 4 * K4_MINW;   // resident wavefronts per CU the register budget of the kernels admits
@@ -393,10 +412,10 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     const size_t lds = fixed + (size_t)nslot * cb * blk;
     typedef void (*kern_t)(EvalArgs);
     static const kern_t kern[2][4] = {
-        {ongpis_eval_kernel<1, false, kQS, K4_NBW>, ongpis_eval_kernel<2, false, kQS, K4_NBW>, ongpis_eval_kernel<4, false, kQS, K4_NBW>,
-         ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW>},
-        {ongpis_eval_kernel<1, true, kQS, K4_NBW>, ongpis_eval_kernel<2, true, kQS, K4_NBW>, ongpis_eval_kernel<4, true, kQS, K4_NBW>,
-         ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW>}};
+        {ongpis_eval_kernel<1, false, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, false, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, false, kQS, K4_NBW, 0>,
+         ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW, K4_WP3>},
+        {ongpis_eval_kernel<1, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, true, kQS, K4_NBW, 0>,
+         ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW, K4_WP3>}};
     const int kidx = wclass < 3 ? wclass : 3;
     static bool attr_set = false;
     if (!attr_set) {
