@@ -221,6 +221,7 @@ def main():
             ts.append(time.perf_counter() - t0)
         cores = os.cpu_count() or 1
         cpu_s = float(np.median(ts))
+        fl = om.test_flags(sub)
         oracle_lib.set_arith_mode("tiled")
         cpu = {"value": sub.shape[0] / cpu_s, "unit": "points/s", "cores": cores, "kind": "port",
                "sample": "%d^3 subsample of the same %d^3 grid after the same %d frames (CPU oracle in its natural-order arithmetic = the "
@@ -232,7 +233,6 @@ def main():
         # (a) against the natural-order run just timed (independent summation order, its own map);
         flat = (idx[:, None, None] * args.grid + idx[None, :, None]) * args.grid + idx[None, None, :]
         rg = res[torch.from_numpy(flat.reshape(-1)).to(dev)].cpu().numpy()
-        fl = om.test_flags(sub)
         cpu["sdf_rmse_vs_oracle_natural_order"] = float(np.sqrt(np.mean((rg[:, 0].astype(np.float64) - ro[:, 0]) ** 2)))
         cpu["map_points_oracle_natural_order"] = om.num_points()
         cpu["branch_ambiguous_in_sample"] = int(((fl & 6) != 0).sum())

@@ -391,6 +391,7 @@ struct OnGPIS {
     std::vector<float> L, alpha;
     std::vector<float> Linv;   // inverted 32x32 diagonal blocks of L (linalg.hpp, fwd_subst_blocked)
     std::vector<float> X;      // tiled mode: explicit inverse X = L^-1, column-major K x K (lower), see train()
+    int mode = ARITH_TILED;    // arithmetic variant the model was trained in: predictions use the same one
 
     OnGPIS(int dim_, float s) : dim(dim_), scale(s), three_over_scale((float)(3.0 / (double)(s * s))) {}
 
@@ -418,6 +419,7 @@ struct OnGPIS {
         }
         L.assign((size_t)K * K, 0.f);
         matern32_train_lower(dim, N, x.data(), gidx.data(), ng, scale, sigx.data(), sigg.data(), L.data(), K);
+        mode = arith_mode();
         chol_lower_m(L.data(), K, K);
         alpha = y;
         fwd_subst_m(L.data(), K, K, alpha.data(), 1, K);
@@ -477,13 +479,13 @@ struct OnGPIS {
         const int nc = 1 + dim;
         std::vector<float> ks((size_t)K * nc);
         matern32_cross1(dim, N, x.data(), gidx.data(), ng, scale, xq, ks.data(), K);
-        if (arith_mode() != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
-            const bool d64 = arith_mode() == ARITH_FP64ACC;
+        if (mode != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
+            const bool d64 = mode == ARITH_FP64ACC;
             for (int c = 0; c < nc; ++c) {
                 const float* col = &ks[(size_t)c * K];
                 mean[c] = d64 ? dot_nat<double>(col, alpha.data(), K) : dot_nat<float>(col, alpha.data(), K);
             }
-            fwd_subst_m(L.data(), K, K, ks.data(), nc, K);
+            if (d64) fwd_subst_nat<double>(L.data(), K, K, ks.data(), nc, K); else fwd_subst_nat<float>(L.data(), K, K, ks.data(), nc, K);
             for (int c = 0; c < nc; ++c) {
                 const float* col = &ks[(size_t)c * K];
                 const float s = d64 ? dot_nat<double>(col, col, K) : dot_nat<float>(col, col, K);
