@@ -23,6 +23,20 @@
 
 using namespace gpis;
 
+// Fine-grained host timing of update() for tools/update_profile.py: only in builds with -DGPIS_UPDATE_TRACE.
+#ifdef GPIS_UPDATE_TRACE
+struct UpdLap {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void operator()(const char* what) {
+        auto n = std::chrono::steady_clock::now();
+        fprintf(stderr, "[upd] %-28s %7.2f ms\n", what, std::chrono::duration<float, std::milli>(n - t).count());
+        t = n;
+    }
+};
+#else
+struct UpdLap { void operator()(const char*) {} };
+#endif
+
 namespace {
 
 inline float occ_test(float rinv, float rinv0, float a) {  // GPisMap3.cpp:38-41
@@ -456,6 +470,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
     const float delx = setting.delx;
     const int n = obs_numdata;
     static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
+    UpdLap ulap;
     // one speculative K2 batch: centre + 6 perturbations per valid pixel
     std::vector<float> q((size_t)14 * n), val((size_t)7 * n, 0.f), var((size_t)7 * n, 1e6f);
     for (int k = 0; k < n; ++k) {
@@ -470,9 +485,14 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
             q[(size_t)14 * k + 3 + 2 * i] = X / Z;
         }
     }
+    ulap("evalPoints: build queries");
     int rc = gpo.query(q.data(), 7 * n, val.data(), var.data(), stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += 7 * (long)n;
+    ulap("evalPoints: K2 batch");
+    // NB (measured, round 2): pre-filtering the pixels with is_not_new() against the tree as it stands before this pass is NOT
+    // exact -- an insert can split a node and move its stored point into a child that no longer contains a later pixel, which
+    // flips that pixel's is_not_new() from true to false (29 996 instead of 30 012 points after frame 2).  The pass stays in order.
 
     for (int k = 0; k < n; ++k) {
         const float* pv = &val[(size_t)7 * k];
@@ -518,10 +538,12 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         for (int d = 0; d < 3; ++d) p.grad[d] = g[d];
         for (int c : ins) activeSet.insert(c);
     }
+    ulap("evalPoints: insert pass");
 }
 
 // -------------------------------------------------------------------- updateGPs ----
 void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
+    UpdLap ulap;
     shard_jobs.clear();
     table_pending = false;
     T3::Set updateSet(activeSet);
@@ -533,6 +555,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     }
     for (int m : tree.released_models) store.release_slot(m);
     tree.released_models.clear();
+    ulap("updateGPs: neighbour sets");
     if (!updateSet.empty()) {
         std::vector<int> todo(updateSet.begin(), updateSet.end());
         std::sort(todo.begin(), todo.end());
@@ -554,6 +577,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
             jobs.push_back(j);
             ids.insert(ids.end(), res.begin(), res.end());
         }
+        ulap("updateGPs: range queries");
         if (!jobs.empty()) {
             // mirror of the map points in HBM: 9 SoA rows indexed by point id
             size_t np = tree.pts.size();
@@ -564,6 +588,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
             }
             int rc = store.upload_points(soa.data(), (int)np, stream);
+            ulap("updateGPs: point mirror");
             if (shard_world > 1) {
                 // Greedy longest-processing-time partition of the frame's clusters by their K^3 factorisation cost
                 // (ties by job order): every rank computes the same owners and trains only its own share.
@@ -588,10 +613,12 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
             } else if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
+            ulap("updateGPs: train_batch");
         }
     }
     activeSet.clear();
     if (!table_pending) build_cluster_table();
+    ulap("updateGPs: cluster table");
 }
 
 void GPisMap3::Impl::build_cluster_table() {

@@ -256,6 +256,13 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     GPIS_HIP(hipMemcpyAsync(d_ids_, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
+    if (!s2_) {   // side streams / events of the size groups (created once, outside the timed interval)
+        GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
+        GPIS_HIP(hipStreamCreateWithFlags(&s3_, hipStreamNonBlocking));
+        GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
+        GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
+        GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
+    }
     if (profile) {
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
@@ -263,13 +270,6 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
     ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
     // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream
-    if (!s2_) {
-        GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
-        GPIS_HIP(hipStreamCreateWithFlags(&s3_, hipStreamNonBlocking));
-        GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
-        GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
-        GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
-    }
     GPIS_HIP(hipEventRecord(evf_, s));
     hipStream_t gs[3] = {s, s3_, s2_};
     for (int grp = 0; grp < 3; ++grp) {
