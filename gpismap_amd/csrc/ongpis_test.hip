@@ -56,6 +56,9 @@ typedef const int __attribute__((address_space(1))) * giptr;
                             // 128 VGPRs: one accumulator tile then lives in scratch (2.8 TB of spill traffic per 256^3 pass) --
                             // F = 5 bench 1379 ms/step with 2 buffers, 1233 ms/step with 1 (107 VGPRs, no scratch)
 #endif
+#ifndef K4_PRIO
+#define K4_PRIO 0            // s_setprio level of a wave while it multiplies (0: none)
+#endif
 #ifndef K4_WP3
 #define K4_WP3 0            // generating-only wavefronts of the widest classes (0: unified).  Measured on the F = 5 bench: 2 of 8
                             // waves generating (6 x 4 rows per group) 1497 ms/step, unified 1360 ms/step
@@ -287,6 +290,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             for (int ci = 0; ci < nch; ++ci, ++gci) {
                 if (WP == 0 && gen_first && !(K4X & 1)) produce_next();
                 {
+                    if (K4_PRIO) __builtin_amdgcn_s_setprio(K4_PRIO);
                     const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
                     const int c0 = ci * CB;
 #pragma unroll
@@ -317,6 +321,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                         }
                     }
                 }
+                if (K4_PRIO) __builtin_amdgcn_s_setprio(0);
                 if (WP == 0 && !gen_first && !(K4X & 1)) produce_next();
                 __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
             }

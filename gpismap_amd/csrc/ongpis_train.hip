@@ -167,40 +167,67 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 __device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 + c; }
 
 // z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2); finally the padding the blocked solves rely on.
+// Right-looking over block columns c = nb-1 .. 0:  wave 0 solves the 32 x 32 triangle L_cc^T a_c = y_c (lane = unknown, its
+// column of the block in registers: the rows cr..cr+31 of column cr+lane are contiguous in the column-major factor), then
+// every thread subtracts L(c, rows above)^T a_c from its rows of y -- again one contiguous 128-byte piece of its column.
+// All loads are unconditional (the padding rows are part of the allocation) and issued before the chain that consumes
+// them; only the arithmetic is predicated on the row being < K.  y lives in LDS (`ybuf`, ycap floats) when it fits.
 template <int NTH>
-__device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* D, float* av, int tid, int lane, int wave) {
+__device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf, int ycap, float* av, int tid, int lane, int wave) {
     const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
-    for (int jj = tid; jj < K; jj += NTH) m.y[jj] = L[K + (size_t)jj * ld];
+    float* yv = (K <= ycap) ? ybuf : m.y;
+    for (int jj = tid; jj < K; jj += NTH) yv[jj] = L[K + (size_t)jj * ld];
+    const int l31 = lane & 31;
+    float4 dq[8];
+    float dg = 1.f;
+    auto load_diag_block = [&](int c) {
+        const int cr = 32 * c;
+        const float4* cp = reinterpret_cast<const float4*>(L + (size_t)cr + (size_t)(cr + l31) * ld);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) dq[q] = cp[q];
+        dg = L[(size_t)(cr + l31) * (ld + 1)];
+    };
+    if (wave == 0) load_diag_block(nb - 1);
     __syncthreads();
     for (int c = nb - 1; c >= 0; --c) {
         const int cr = 32 * c;
         if (wave == 0) {
-            if (lane < 32)
-                for (int cc = 0; cc < 32; ++cc) D[lane * 33 + cc] = L[(cr + lane) + (size_t)(cr + cc) * ld];
-            __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_wave_barrier();
-            volatile float* Dv = D;
-            float b = (lane < 32 && cr + lane < K) ? m.y[cr + lane] : 0.f;
+            float dcol[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dcol[4 * q] = dq[q].x; dcol[4 * q + 1] = dq[q].y; dcol[4 * q + 2] = dq[q].z; dcol[4 * q + 3] = dq[q].w; }
+            float b = (cr + l31 < K) ? yv[cr + l31] : 0.f;
+            const float dd = (cr + l31 < K) ? dg : 1.f;
+#pragma unroll
             for (int k = 31; k >= 0; --k) {
                 if (cr + k >= K) continue;
-                float t = b / Dv[(lane & 31) * 33 + (lane & 31)];
-                float ak = __shfl(t, k);
-                if (lane == k) b = ak;
-                if (lane < k) b = fmaf(-Dv[k * 33 + lane], ak, b);
+                const float t = b / dd;
+                const float ak = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), k));
+                if (l31 == k) b = ak;
+                if (l31 < k) b = fmaf(-dcol[k], ak, b);
             }
             if (lane < 32) {
                 av[lane] = (cr + lane < K) ? b : 0.f;
                 if (cr + lane < K) m.alpha[cr + lane] = b;
             }
+            if (c > 0) load_diag_block(c - 1);     // in flight during the update below
         }
         __syncthreads();
         for (int jj = tid; jj < cr; jj += NTH) {
-            float s = m.y[jj];
-            const float* col = L + (size_t)cr + (size_t)jj * ld;
-            for (int k = 31; k >= 0; --k)
-                if (cr + k < K) s = fmaf(-col[k], av[k], s);
-            m.y[jj] = s;
+            float s = yv[jj];
+            const float4* cp = reinterpret_cast<const float4*>(L + (size_t)cr + (size_t)jj * ld);
+            float4 cq[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) cq[q] = cp[q];
+#pragma unroll
+            for (int q = 7; q >= 0; --q) {
+                const int k = 4 * q;
+                if (cr + k + 3 < K) s = fmaf(-cq[q].w, av[k + 3], s);
+                if (cr + k + 2 < K) s = fmaf(-cq[q].z, av[k + 2], s);
+                if (cr + k + 1 < K) s = fmaf(-cq[q].y, av[k + 1], s);
+                if (cr + k < K) s = fmaf(-cq[q].x, av[k], s);
+            }
+            yv[jj] = s;
         }
         __syncthreads();
     }
@@ -220,8 +247,14 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* D, f
     }
 }
 
+#ifndef K3_T1_NT
+#define K3_T1_NT 3      // tiles per wavefront and round, one-wavefront tier (K <= 256)
+#endif
+#ifndef K3_T1_MINW
+#define K3_T1_MINW 2    // wavefronts per SIMD the one-wavefront tier is compiled for
+#endif
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
                                                               const int* __restrict__ d_jobs) {
     __shared__ __attribute__((aligned(16))) float D[32 * 33];       // diagonal tile, row-major padded (factor workspace)
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];      // factored diagonal tile, column-major (for the solves)
@@ -250,6 +283,14 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
         }
     };
 
+#ifdef K3_TRACE
+    __shared__ long long stamps[256];
+    int nst = 0;
+#define K3_STAMP() do { if (blockIdx.x == 7 && tid == 0 && nst < 256) stamps[nst++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define K3_STAMP() do {} while (0)
+#endif
+    K3_STAMP();
     for (int j = 0; j < nb; ++j) {
         const int pw = min(32, K - 32 * j);
         for (int t0 = 0; j + wave + NW * t0 < nbr || (t0 == 0); t0 += NT) {
@@ -269,6 +310,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
                     for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
                 }
             }
+            K3_STAMP();   // A: accumulators loaded
             if (act[0]) {
                 // Panel operands: a_ = -L(j, p) (sign flipped at the matrix instruction), bq = -L(bi, p).  The
                 // panel loop is blocked by PB: every load of a trip is issued AND consumed inside it (fully
@@ -304,6 +346,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
                     }
                 }
             }
+            K3_STAMP();   // B: panel products done
             // ---- diagonal tile: wave 0, first round
             if (t0 == 0) {
                 if (wave == 0) {
@@ -372,6 +415,7 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
                 }
                 __syncthreads();
             }
+            K3_STAMP();   // C: diagonal factorised
             // ---- other tiles: X = T L_jj^{-T}, then store column-major and re-tiled
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -415,10 +459,17 @@ __global__ __launch_bounds__(64 * NW, 2) void ongpis_chol_kernel(const ClusterMo
             }
             if (j + wave + NW * (t0 + NT) >= nbr && t0 > 0) { /* loop condition handles exit */ }
         }
+        K3_STAMP();   // D: tiles solved and stored
         __syncthreads();   // column j complete: Lt tiles visible, Lc reusable
     }
 
-    chol_epilogue<64 * NW>(m, D, av, tid, lane, wave);
+    K3_STAMP();
+    chol_epilogue<64 * NW>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
+    K3_STAMP();
+#ifdef K3_TRACE
+    if (blockIdx.x == 7 && tid == 0) { for (int i = 1; i < nst; ++i) printf("%d:%lld ", i, stamps[i] - stamps[i - 1]); printf("\nK=%d nb=%d total %lld\n", K, nb, stamps[nst - 1] - stamps[0]); }
+#endif
+#undef K3_STAMP
 }
 
 
@@ -638,7 +689,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     }
     if (g != 0) return;
     wait_flag(alldone, G);
-    chol_epilogue<512>(m, D, av, tid, lane, wave);
+    chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -793,7 +844,7 @@ void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s) {
     // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small
     // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
-    if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<3, 1>), dim3(njobs), dim3(64), 0, s, d_models, d_jobs);
+    if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<K3_T1_NT, 1>), dim3(njobs), dim3(64), 0, s, d_models, d_jobs);
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
