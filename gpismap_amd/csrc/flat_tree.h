@@ -31,6 +31,21 @@ struct FlatPoint {  // reference Node / Node3, strct.h:69-129
     bool alive;
 };
 
+// The cluster cells one insert() reports (the cell on the new point's path, and the one a displaced point lands in):
+// a couple of ids at most -- kept inline, no allocation per inserted point.
+struct SmallIdSet {
+    int v[6];
+    int n = 0;
+    std::vector<int> more;
+    void insert(int x) {
+        for (int i = 0; i < n; ++i) if (v[i] == x) return;
+        for (int y : more) if (y == x) return;
+        if (n < 6) v[n++] = x; else more.push_back(x);
+    }
+    bool empty() const { return n == 0; }
+    template <class F> void for_each(F f) const { for (int i = 0; i < n; ++i) f(v[i]); for (int y : more) f(y); }
+};
+
 template <int DIM>
 class FlatTree {
 public:
@@ -46,6 +61,7 @@ public:
         bool leaf, maxDepth, rootLimit, alive;
     };
     using Set = std::unordered_set<int>;
+    using InsSet = SmallIdSet;
 
     explicit FlatTree(const FlatTreeParam& p) : prm(p) {}
 
@@ -85,7 +101,8 @@ public:
     bool empty_leaf(int n) const { return nodes[n].leaf && nodes[n].pt < 0; }
 
     // octree.cpp:214-293 / :295-411.  quads == nullptr selects the set-less variant.
-    bool insert(int n, int pid, Set* quads) {
+    template <class S>
+    bool insert(int n, int pid, S* quads) {
         const float* p = pts[pid].pos;
         if (!contains(n, p)) {
             if (nodes[n].par < 0) return nodes[n].rootLimit ? false : insert_to_parent(n, pid);
@@ -111,12 +128,15 @@ public:
                 if (sqdist(pts[old].pos, p) < prm.min_half_sq) return false;
                 subdivide(n, -1);
                 bool kept = false;
-                for (int i = 0; i < NC; ++i) if (insert(nodes[n].ch[i], old, quads)) { kept = true; break; }
+                const float* po = pts[old].pos;
+                const int oo = only_child(n, po);
+                for (int i = (oo < 0 ? 0 : oo); i < (oo < 0 ? NC : oo + 1); ++i) if (insert(nodes[n].ch[i], old, quads)) { kept = true; break; }
                 if (!kept) drop_point(old);  // on a child boundary: the reference loses it too
                 nodes[n].pt = -1;
             }
         }
-        for (int i = 0; i < NC; ++i)
+        const int only = only_child(n, p);
+        for (int i = (only < 0 ? 0 : only); i < (only < 0 ? NC : only + 1); ++i)
             if (insert(nodes[n].ch[i], pid, quads)) {
                 if (quads && at_cluster(n)) quads->insert(n);
                 return true;
@@ -126,11 +146,18 @@ public:
 
     bool is_not_new(int n, const float* p) const {  // octree.cpp:431-460
         if (!contains(n, p)) return false;
-        if (empty_leaf(n)) return false;
-        if (nodes[n].pt >= 0 && sqdist(pts[nodes[n].pt].pos, p) < prm.min_half_sq) return true;
-        if (nodes[n].leaf) return false;
-        for (int i = 0; i < NC; ++i) if (is_not_new(nodes[n].ch[i], p)) return true;
-        return false;
+        for (;;) {
+            if (empty_leaf(n)) return false;
+            if (nodes[n].pt >= 0 && sqdist(pts[nodes[n].pt].pos, p) < prm.min_half_sq) return true;
+            if (nodes[n].leaf) return false;
+            const int i = only_child(n, p);
+            if (i < 0) {  // next to a splitting plane: the reference's loop over all children
+                for (int k = 0; k < NC; ++k) if (is_not_new(nodes[n].ch[k], p)) return true;
+                return false;
+            }
+            n = nodes[n].ch[i];
+            if (!contains(n, p)) return false;
+        }
     }
 
     // octree.cpp:462-508 (set == nullptr: every child visited) / :510-566.  Removes the point
@@ -145,7 +172,8 @@ public:
         }
         if (nodes[n].leaf) return false;
         bool res = false;
-        for (int i = 0; i < NC; ++i) {
+        const int only = only_child(n, p);
+        for (int i = (only < 0 ? 0 : only); i < (only < 0 ? NC : only + 1); ++i) {
             if (set) { if (!res) res |= remove(nodes[n].ch[i], p, set); }
             else res |= remove(nodes[n].ch[i], p, nullptr);
         }
@@ -202,6 +230,24 @@ private:
         const TNode& t = nodes[n];
         for (int d = 0; d < DIM; ++d) if (hi[d] < t.lo[d] || lo[d] > t.hi[d]) return false;
         return true;
+    }
+    // The one child whose box can contain p, or -1 when p lies so close to a splitting plane of node n that the rounding
+    // of the child boxes (centre -/+ l -/+ l in float) could matter: then the caller visits all children in the reference's
+    // order.  Every child-visiting routine above fails immediately on a child that does not (strictly) contain p, so going
+    // straight to the only candidate gives the same result and side effects as the reference's loop -- one node touched
+    // per level instead of 2^DIM.
+    int only_child(int n, const float* p) const {
+        const TNode& t = nodes[n];
+        int i = 0;
+        for (int d = 0; d < DIM; ++d) {
+            const float dd = p[d] - t.c[d];
+            const float tol = 1e-5f * (std::fabs(t.c[d]) + t.h);
+            if (!(std::fabs(dd) > tol)) return -1;
+            // child_center(): bit 0 set = +x; bit 1 set = -y; bit 2 set = -z
+            if (d == 0) { if (dd > 0.f) i |= 1; }
+            else if (dd < 0.f) i |= (1 << d);
+        }
+        return i;
     }
     bool at_cluster(int n) const { return std::fabs((double)(nodes[n].h - prm.cluster_half)) < prm.cluster_eps; }
 
@@ -266,7 +312,7 @@ private:
             nodes[p].ch[slot] = n;
         }  // else: reference quirk -- a childless parent centred at the origin; the old tree is orphaned
         nodes[n].par = p;
-        return insert(p, pid, nullptr);
+        return insert(p, pid, (Set*)nullptr);
     }
     void query_range_rec(int n, const float* c, float hsq, const float* lo, const float* hi, std::vector<int>& out) const {
         if (!intersects(n, lo, hi) || empty_leaf(n)) return;

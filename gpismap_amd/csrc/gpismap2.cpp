@@ -93,7 +93,7 @@ struct GPisMap::Impl {
     void updateMapPoints();
     void evalPoints();
     void updateGPs();
-    int try_insert(int pid, T2::Set& ins);
+    int try_insert(int pid, T2::InsSet& ins);
 
     struct Work {        // state of one point during re-evaluation
         bool go = false;
@@ -139,7 +139,7 @@ bool GPisMap::Impl::preproData(const float* datax, const float* dataf, int N, co
     return obs_numdata > 1;
 }
 
-int GPisMap::Impl::try_insert(int pid, T2::Set& ins) {  // GPisMap.cpp:433-443 / :497-507
+int GPisMap::Impl::try_insert(int pid, T2::InsSet& ins) {  // GPisMap.cpp:433-443 / :497-507
     bool ok_ = false;
     if (!tree.is_not_new(tree.root, tree.pts[pid].pos)) {
         ok_ = tree.insert(tree.root, pid, &ins);
@@ -317,12 +317,12 @@ void GPisMap::Impl::reeval_apply(int pid, const Work& s) {  // GPisMap.cpp:319-4
     tree.remove(tree.root, nd.pos, &activeSet);
     if ((double)noise > 1.0 && (double)grad_noise > 0.61) return;
     int np = tree.new_point(pos_new);
-    T2::Set ins;
+    T2::InsSet ins;
     if (try_insert(np, ins) != 2) return;
     FlatPoint<2>& p = tree.pts[np];
     p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
     p.grad[0] = grad_new[0]; p.grad[1] = grad_new[1];
-    for (int c : ins) activeSet.insert(c);
+    ins.for_each([&](int c) { activeSet.insert(c); });
 }
 
 void GPisMap::Impl::updateMapPoints() {  // GPisMap.cpp:181-233
@@ -396,7 +396,7 @@ void GPisMap::Impl::evalPoints() {  // GPisMap.cpp:466-572
         const float* pr = &var[(size_t)5 * k];
         if (pr[0] > setting.obs_var_thre) continue;
         int pid = tree.new_point(&obs_xyglobal[2 * (size_t)k]);
-        T2::Set ins;
+        T2::InsSet ins;
         if (try_insert(pid, ins) != 2) continue;
         float occ[4] = {-1, -1, -1, -1};
         float occ_mean = 0.f;
@@ -429,7 +429,7 @@ void GPisMap::Impl::evalPoints() {  // GPisMap.cpp:466-572
         FlatPoint<2>& p = tree.pts[pid];
         p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
         p.grad[0] = g[0]; p.grad[1] = g[1];
-        for (int c : ins) activeSet.insert(c);
+        ins.for_each([&](int c) { activeSet.insert(c); });
     }
 }
 

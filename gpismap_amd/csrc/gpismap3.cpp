@@ -143,7 +143,7 @@ struct GPisMap3::Impl {
     void updateMapPoints();
     void evalPoints();
     void updateGPs();
-    int try_insert(int pid, T3::Set& ins);
+    int try_insert(int pid, T3::InsSet& ins);
 
     struct Stage2 {   // per point, after the centre query
         bool go = false;        // survives the var / occupancy gates
@@ -222,7 +222,7 @@ bool GPisMap3::Impl::regressObs() {  // :239-256 -> K1
 // reported (the caller then fills in its data), 1 when it was stored through the set-less
 // root-growth path (octree.cpp:151-212: it stays in the tree with default data, as in the
 // reference), 0 when it was not stored (the point object is released).
-int GPisMap3::Impl::try_insert(int pid, T3::Set& ins) {
+int GPisMap3::Impl::try_insert(int pid, T3::InsSet& ins) {
     bool ok_ = false;
     if (!tree.is_not_new(tree.root, tree.pts[pid].pos)) {
         ok_ = tree.insert(tree.root, pid, &ins);
@@ -392,12 +392,12 @@ void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, c
     tree.remove(tree.root, nd.pos, &activeSet);
     if ((double)noise > 1.0 && (double)grad_noise > 0.61) return;
     int np = tree.new_point(pos_new);
-    T3::Set ins;
+    T3::InsSet ins;
     if (try_insert(np, ins) != 2) return;
     FlatPoint<3>& p = tree.pts[np];
     p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
     for (int d = 0; d < 3; ++d) p.grad[d] = grad_new[d];
-    for (int c : ins) activeSet.insert(c);
+    ins.for_each([&](int c) { activeSet.insert(c); });
 }
 
 // ------------------------------------------------------------ updateMapPoints ----
@@ -499,7 +499,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         const float* pr = &var[(size_t)7 * k];
         if (pr[0] > setting.obs_var_thre) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
-        T3::Set ins;
+        T3::InsSet ins;
         if (try_insert(pid, ins) != 2) continue;
         const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
         float occ[6] = {-1, -1, -1, -1, -1, -1};
@@ -536,7 +536,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         FlatPoint<3>& p = tree.pts[pid];
         p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
         for (int d = 0; d < 3; ++d) p.grad[d] = g[d];
-        for (int c : ins) activeSet.insert(c);
+        ins.for_each([&](int c) { activeSet.insert(c); });
     }
     ulap("evalPoints: insert pass");
 }

@@ -217,6 +217,20 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         for (int g = 0; g < G; ++g) { cwork.push_back(j); cwork.push_back(g); cwork.push_back(G); }
         ncoop = j + 1;
     }
+#ifdef GPIS_UPDATE_TRACE
+    {   // size profile of the batch: block rows per cluster, by group
+        int hist[3][12] = {};
+        for (int j = 0; j < nj; ++j) {
+            const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+            hist[j < ncoop ? 0 : (j < n0 ? 1 : 2)][std::min(11, nbj / 8)]++;
+        }
+        for (int g = 0; g < 3; ++g) {
+            fprintf(stderr, "[train] group %d (%s):", g, g == 0 ? "cooperative" : (g == 1 ? "8 waves" : "1 wave"));
+            for (int b = 0; b < 12; ++b) if (hist[g][b]) fprintf(stderr, "  nb %d-%d: %d", 8 * b, 8 * b + 7, hist[g][b]);
+            fprintf(stderr, "   coop workgroups %d\n", (int)cwork.size() / 3);
+        }
+    }
+#endif
     // K3b work lists per group: one entry per (job, block column); columns longer than kLongCol rows first (a workgroup
     // of 8 pipelined wavefronts each), the rest one wavefront per column
     constexpr int kLongCol = 24;

@@ -293,13 +293,21 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
     K3_STAMP();
     for (int j = 0; j < nb; ++j) {
         const int pw = min(32, K - 32 * j);
-        for (int t0 = 0; j + wave + NW * t0 < nbr || (t0 == 0); t0 += NT) {
+        // Tile rows of block column j -> wavefronts.  With 8 wavefronts, wave 0 takes ONLY the diagonal tile and the others
+        // share the rows below it: the diagonal's panel products and its (serial) factorisation then run while the other
+        // wavefronts do their panel products, instead of after wave 0's share of them.
+        auto tile_row = [&](int idx) -> int {
+            if (NW == 1) return j + idx;
+            if (wave == 0) return idx == 0 ? j : nbr;
+            return j + wave + (NW - 1) * idx;
+        };
+        for (int t0 = 0; tile_row(t0) < nbr || (t0 == 0); t0 += NT) {
             // ---- accumulate: acc[tt] = A(bi, j) - sum_p L(bi, p) L(j, p)^T (transposed: lane = row, regs = cols)
             f32x16 acc[NT];
             bool act[NT];
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                const int bi = j + wave + NW * (t0 + tt);
+                const int bi = tile_row(t0 + tt);
                 act[tt] = bi < nbr;
                 if (act[tt]) {
                     const float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                     float a_[2][16];
                     float bq[2][16];
                     auto issue_b = [&](float (&dst)[16], int tt, int p) {
-                        if (act[tt] && p < j) load_tile(dst, j + wave + NW * (t0 + tt), p, 0u);
+                        if (act[tt] && p < j) load_tile(dst, tile_row(t0 + tt), p, 0u);
                     };
                     load_tile(a_[0], j, p0, 0u);
                     issue_b(bq[0], 0, p0);
@@ -419,7 +427,7 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
             // ---- other tiles: X = T L_jj^{-T}, then store column-major and re-tiled
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
-                const int bi = j + wave + NW * (t0 + tt);
+                const int bi = tile_row(t0 + tt);
                 if (t0 == 0 && tt == 0 && wave == 0) {
                     // inv(L_jj) for K4 (V_c = inv(L_cc) U_c on the matrix cores): forward substitution on the unit
                     // vectors, stored as the diagonal tile of Lt in the order K4's MFMA A operand reads it --
@@ -457,7 +465,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                     }
                 }
             }
-            if (j + wave + NW * (t0 + NT) >= nbr && t0 > 0) { /* loop condition handles exit */ }
         }
         K3_STAMP();   // D: tiles solved and stored
         __syncthreads();   // column j complete: Lt tiles visible, Lc reusable

@@ -187,3 +187,19 @@ def test_cpp_surface_builds_with_the_gateway_flags(tmp_path):
     if gpismap_amd.device_count() < 1:
         assert "map3 ok 0" in r.stdout and "map2 ok 0" in r.stdout
         assert "HIP device unavailable" in r.stderr
+
+
+def test_flat_tree_matches_oracle_tree(tmp_path):
+    """Host spatial index: the product's flat tree (one child visited per level where the reference loops over all
+    2^d) against the oracle's restatement of octree.cpp / quadtree.cpp on random insert / remove / range-query
+    sequences with near-duplicates, points ON splitting planes and root growth -- every return value and the
+    traversal order of the stored points must be identical (tests/cpp/tree_check.cpp)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tree_check")
+    r = subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "gpismap_amd", "csrc"), "-I" + os.path.join(root, "oracle"),
+                        os.path.join(root, "tests", "cpp", "tree_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, "30000"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("identical") == 12 and "MISMATCH" not in r.stdout
