@@ -249,6 +249,22 @@ private:
         }
         return i;
     }
+    // Bit i set = child i of node n certainly fails intersects(lo, hi): its box lies entirely on the far side of one of
+    // n's splitting planes, by more than the rounding of the child boxes.  The range walks skip those children without
+    // touching their nodes; every child that is visited still gets the reference's exact inclusive test.
+    int children_outside(int n, const float* lo, const float* hi) const {
+        const TNode& t = nodes[n];
+        int skip = 0;
+        for (int d = 0; d < DIM; ++d) {
+            const float tol = 1e-5f * (std::fabs(t.c[d]) + t.h);
+            // child_center(): bit 0 set = +x; bit 1 set = -y; bit 2 set = -z
+            const int plus_mask = (d == 0) ? 0xAA : (d == 1 ? 0x33 : 0x0F);   // children on the + side of axis d
+            const int all = (1 << NC) - 1;
+            if (hi[d] < t.c[d] - tol) skip |= plus_mask & all;             // range entirely below the plane: + children out
+            else if (lo[d] > t.c[d] + tol) skip |= (~plus_mask) & all;     // entirely above: - children out
+        }
+        return skip;
+    }
     bool at_cluster(int n) const { return std::fabs((double)(nodes[n].h - prm.cluster_half)) < prm.cluster_eps; }
 
     int alloc_node(const float* c, float h, int par) {
@@ -320,7 +336,8 @@ private:
             if (sqdist(pts[nodes[n].pt].pos, c) < hsq) out.push_back(nodes[n].pt);
             return;
         }
-        for (int i = 0; i < NC; ++i) query_range_rec(nodes[n].ch[i], c, hsq, lo, hi, out);
+        const int skip = children_outside(n, lo, hi);
+        for (int i = 0; i < NC; ++i) if (!((skip >> i) & 1)) query_range_rec(nodes[n].ch[i], c, hsq, lo, hi, out);
     }
     void query_clusters_rec(int n, const float* c, const float* lo, const float* hi, std::vector<int>& out,
                             std::vector<float>* sq) const {
@@ -328,7 +345,8 @@ private:
         const TNode& t = nodes[n];
         if (t.leaf && (double)t.h > (double)prm.cluster_half + (sq ? prm.qleaf_eps_dist : prm.qleaf_eps_plain)) return;
         if ((double)t.h > (double)prm.cluster_half + prm.qdesc_eps) {
-            for (int i = 0; i < NC; ++i) query_clusters_rec(t.ch[i], c, lo, hi, out, sq);
+            const int skip = children_outside(n, lo, hi);
+            for (int i = 0; i < NC; ++i) if (!((skip >> i) & 1)) query_clusters_rec(t.ch[i], c, lo, hi, out, sq);
         } else {
             if (sq) sq->push_back(sqdist(t.c, c));
             out.push_back(n);

@@ -241,7 +241,9 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     st.assign(n, Stage2());
     pval.assign((size_t)6 * n, 0.f); pvar.assign((size_t)6 * n, 1e6f);
     if (n == 0) return;
-    std::vector<float> q((size_t)2 * n), val(n, 0.f), var(n, 1e6f);
+    // both K2 batches go through the ObsGP object's page-locked staging, sized once for the larger (6 n) one
+    float* q = gpo.stage_q(6 * n);
+    if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
     std::vector<char> front(n, 0);
     std::vector<std::array<float, 3>> loc(n);
     for (int i = 0; i < n; ++i) {
@@ -254,11 +256,14 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
         q[2 * i] = front[i] ? y_loc / z_loc : 1e30f;  // behind the camera: never queried by the reference
         q[2 * i + 1] = front[i] ? x_loc / z_loc : 1e30f;
     }
-    int rc = gpo.query(q.data(), n, val.data(), var.data(), stream);
+    int rc = gpo.query_staged(n, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += n;
     const float delx = setting.delx;
-    std::vector<float> q2((size_t)12 * n, 1e30f);
+    // centre answers: copied out, the staging is reused for the perturbation batch
+    std::vector<float> val(gpo.staged_val(), gpo.staged_val() + n), var(gpo.staged_var(), gpo.staged_var() + n);
+    float* q2 = q;
+    std::fill(q2, q2 + (size_t)12 * n, 1e30f);
     for (int i = 0; i < n; ++i) {
         if (!front[i]) continue;
         if (var[i] > setting.obs_var_thre) continue;
@@ -300,8 +305,10 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
             q2[(size_t)12 * i + 2 * k + 1] = X / Z;
         }
     }
-    rc = gpo.query(q2.data(), 6 * n, pval.data(), pvar.data(), stream);
-    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
+    rc = gpo.query_staged(6 * n, stream);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
+    pval.assign(gpo.staged_val(), gpo.staged_val() + (size_t)6 * n);
+    pvar.assign(gpo.staged_var(), gpo.staged_var() + (size_t)6 * n);
     stat_obs_queries += 6 * (long)n;
 }
 
@@ -472,7 +479,8 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
     static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
     UpdLap ulap;
     // one speculative K2 batch: centre + 6 perturbations per valid pixel
-    std::vector<float> q((size_t)14 * n), val((size_t)7 * n, 0.f), var((size_t)7 * n, 1e6f);
+    float* q = gpo.stage_q(7 * n);   // page-locked staging of the ObsGP object: filled in place, answers read in place
+    if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
     for (int k = 0; k < n; ++k) {
         const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
         q[(size_t)14 * k] = obs_valid_v[k];
@@ -486,9 +494,11 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         }
     }
     ulap("evalPoints: build queries");
-    int rc = gpo.query(q.data(), 7 * n, val.data(), var.data(), stream);
+    int rc = gpo.query_staged(7 * n, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += 7 * (long)n;
+    const float* val = gpo.staged_val();
+    const float* var = gpo.staged_var();
     ulap("evalPoints: K2 batch");
     // NB (measured, round 2): pre-filtering the pixels with is_not_new() against the tree as it stands before this pass is NOT
     // exact -- an insert can split a node and move its stored point into a child that no longer contains a later pixel, which

@@ -42,6 +42,13 @@ public:
     // are pre-filled by the caller (untouched when no group answers).
     int query(const float* q, int nq, float* val, float* var, hipStream_t s);
     int query_device(const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s);
+    // update()'s batches: the caller writes its queries straight into page-locked staging (stage_q), query_staged()
+    // moves them with true DMA transfers, zero-fills the values on the device (every map caller starts from val = 0)
+    // and leaves the answers in staged_val()/staged_var() until the next stage_q().
+    float* stage_q(int nq);
+    int query_staged(int nq, hipStream_t s);
+    const float* staged_val() const { return h_val_; }
+    const float* staged_var() const { return h_var_; }
     bool trained() const { return trained_; }
     int mode() const { return view_.mode; }
     int ngroups() const { return view_.ngroups; }
@@ -69,6 +76,8 @@ private:
     float* d_tab_ = nullptr;    // vali, valj packed
     int cap_idx_ = 0, cap_tab_ = 0;
     float *d_q_ = nullptr, *d_val_ = nullptr, *d_var_ = nullptr;
+    float *h_q_ = nullptr, *h_val_ = nullptr, *h_var_ = nullptr;   // page-locked staging
+    int cap_hq_ = 0;
 };
 
 }  // namespace gpis

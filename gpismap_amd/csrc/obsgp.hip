@@ -114,8 +114,7 @@ __global__ __launch_bounds__(64) void obsgp_train_kernel(ObsGPView v) {
 }
 
 // ---------------------------------------------------------------------------
-// K2.  One wavefront per query; 4 queries per 256-thread block.
-// Group lookup reproduces ObsGP.cpp:359-406 (2-D) / :154-183 (1-D) exactly.
+// K2.  Group lookup reproduces ObsGP.cpp:359-406 (2-D) / :154-183 (1-D) exactly.
 // Outputs val (untouched when no group answers) and var (1e6 then).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ int obsgp_lookup2(const ObsGPView& v, float q0, float q1) {
@@ -142,42 +141,91 @@ __device__ __forceinline__ int obsgp_lookup1(const ObsGPView& v, float q0) {
     return -1;
 }
 
-__global__ __launch_bounds__(256) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
-                                                          float* __restrict__ val, float* __restrict__ var) {
-    const int lane = threadIdx.x & 63;
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (qi >= nq) return;
-    float q0, q1 = 0.f;
-    if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
-    else q0 = q[qi];
-    int g = (v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0);
-    g = __builtin_amdgcn_readfirstlane(g);
-    if (g < 0) { if (lane == 0) var[qi] = 1e6f; return; }
-    const int n = v.tn[g];
+// K2, lanes = queries.  A wavefront takes 64 consecutive queries, looks their groups up (lane = query) and then serves
+// one DISTINCT group at a time: the group's factor (n columns, <= 16 KB), inputs and alpha are staged in LDS once, and every
+// lane whose query belongs to the group runs the whole prediction for its own query with the k* vector in registers --
+//   k_i = OU(x_i, q),  mean = tree sum of k_i alpha_i,  forward substitution  v_j = k_j / L_jj ; k_i -= L_ij v_j (i > j),
+//   var = (1 + noise) - sum v_j^2
+// The operations per query are exactly the ones of the one-wavefront-per-query formulation (chains (O1), (O5), the 64-slot
+// butterfly (O4) written out as the same pairwise tree), so the results are bit-identical to it; but the factor is read
+// once per (wavefront, group) instead of once per query, and the substitution costs ~45 instructions per query instead of
+// ~1200.  update()'s batches are coherent (the 7 queries of a pixel and its neighbours share a group), so a wavefront
+// usually sees one to three groups.  Worst case (64 different groups) it degenerates to one group per pass.
+__global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
+                                                         float* __restrict__ val, float* __restrict__ var) {
+    // one 16 KB buffer, used twice per group: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those
+    // are in registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j))
+    __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sx[128];
+    __shared__ __attribute__((aligned(16))) float sa[64];
+    const int lane = threadIdx.x;
+    const int qi = blockIdx.x * 64 + lane;
+    const bool have = qi < nq;
+    float q0 = 0.f, q1 = 0.f;
+    if (have) {
+        if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
+        else q0 = q[qi];
+    }
+    int g = -1;
+    if (have) g = (v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0);
+    if (have && g < 0) var[qi] = 1e6f;
+    bool pending = have && g >= 0;
     const float a = 1 / OU_SCALE;
-    const float* tx = v.tx + (size_t)g * 128;
-    const float* tL = v.tL + (size_t)g * 4096;
-    float k = 0.f, p = 0.f;
-    if (lane < n) {
-        k = d_ou_k(d_dist2(tx[2 * lane], tx[2 * lane + 1], q0, q1), a);
-        p = k * v.talpha[(size_t)g * 64 + lane];
-    }
-    // mean: 64-slot xor butterfly (order O4)
-    for (int off = 32; off >= 1; off >>= 1) p = p + __shfl_xor(p, off);
-    // variance: forward substitution, chain (O1); acc chain (O5)
-    float acc = 0.f;
-    float col = tL[lane];
-    for (int j = 0; j < n; ++j) {
-        float nxt = (j + 1 < n) ? tL[(j + 1) * 64 + lane] : 0.f;
-        float t = k / col;          // lane j holds k_j / L_jj
-        float vj = __shfl(t, j);
-        if (lane > j) k = fmaf(col, -vj, k);
-        acc = fmaf(vj, vj, acc);
-        col = nxt;
-    }
-    if (lane == 0) {
-        val[qi] = p;
-        var[qi] = (1 + OU_NOISE) - acc;  // ObsGP.cpp:61
+    for (;;) {
+        const unsigned long long todo = __ballot(pending);
+        if (todo == 0ull) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const int gt = __builtin_amdgcn_readlane(g, leader);
+        const int n = v.tn[gt];
+        const bool mine = pending && g == gt;
+        sx[lane] = v.tx[(size_t)gt * 128 + lane];
+        sx[64 + lane] = v.tx[(size_t)gt * 128 + 64 + lane];
+        sa[lane] = v.talpha[(size_t)gt * 64 + lane];
+        __syncthreads();
+        // cross-covariances in a rolled loop (the exp sequence stays compact), parked in LDS, then into registers
+        if (mine) {
+#pragma unroll 1
+            for (int i = 0; i < n; ++i) sbuf[i * 64 + lane] = d_ou_k(d_dist2(sx[2 * i], sx[2 * i + 1], q0, q1), a);
+        }
+        float k[64];
+#pragma unroll
+        for (int i = 0; i < 64; ++i) k[i] = (i < n) ? sbuf[i * 64 + lane] : 0.f;   // (lanes that are not `mine` read stale values: unused)
+        __syncthreads();
+        {   // the group's factor: n columns, 16-byte pieces
+            const float4* src = reinterpret_cast<const float4*>(v.tL + (size_t)gt * 4096);
+            float4* dst = reinterpret_cast<float4*>(sbuf);
+            for (int c = lane; c < n * 16; c += 64) dst[c] = src[c];
+        }
+        __syncthreads();
+        if (mine) {
+            // mean: the xor butterfly of the 64 products as a register tree (order O4)
+            float s[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const float pa = k[i] * sa[i], pb = k[i + 32] * sa[i + 32];
+                s[i] = pa + pb;
+            }
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+                for (int i = 0; i < off; ++i) s[i] = s[i] + s[i + off];
+            // variance: forward substitution, chain (O1); accumulation chain (O5)
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 64; ++j) {
+                if (j < n) {   // wave-uniform
+                    const float vj = k[j] / sbuf[j * 64 + j];
+#pragma unroll
+                    for (int i = j + 1; i < 64; ++i) k[i] = fmaf(sbuf[j * 64 + i], -vj, k[i]);
+                    acc = fmaf(vj, vj, acc);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one column's operands at a time
+            }
+            val[qi] = s[0];
+            var[qi] = (1 + OU_NOISE) - acc;  // ObsGP.cpp:61
+        }
+        pending = pending && !mine;
+        __syncthreads();
     }
 }
 
@@ -186,7 +234,7 @@ void obsgp_launch_train(const ObsGPView& v, hipStream_t s) {
 }
 void obsgp_launch_query(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s) {
     if (nq <= 0) return;
-    hipLaunchKernelGGL(obsgp_query_kernel, dim3((nq + 3) / 4), dim3(256), 0, s, v, d_q, nq, d_val, d_var);
+    hipLaunchKernelGGL(obsgp_query_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, v, d_q, nq, d_val, d_var);
 }
 
 }  // namespace gpis

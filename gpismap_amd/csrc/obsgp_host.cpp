@@ -73,6 +73,7 @@ ObsGPDevice::ObsGPDevice() { std::memset(&view_, 0, sizeof(view_)); }
 ObsGPDevice::~ObsGPDevice() {
     (void)hipFree(d_x_); (void)hipFree(d_f_); (void)hipFree(d_idx_); (void)hipFree(d_tab_);
     (void)hipFree(d_q_); (void)hipFree(d_val_); (void)hipFree(d_var_);
+    (void)hipHostFree(h_q_); (void)hipHostFree(h_val_); (void)hipHostFree(h_var_);
     (void)hipFree(view_.tn); (void)hipFree(view_.tx); (void)hipFree(view_.talpha); (void)hipFree(view_.tL);
 }
 
@@ -232,6 +233,36 @@ int ObsGPDevice::query(const float* q, int nq, float* val, float* var, hipStream
     GPIS_HIP(hipGetLastError());
     GPIS_HIP(hipMemcpyAsync(val, d_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipMemcpyAsync(var, d_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    return GPIS_OK;
+}
+
+float* ObsGPDevice::stage_q(int nq) {
+    if (nq > cap_hq_) {
+        (void)hipHostFree(h_q_); (void)hipHostFree(h_val_); (void)hipHostFree(h_var_);
+        h_q_ = h_val_ = h_var_ = nullptr; cap_hq_ = 0;
+        const int cap = nq + nq / 4 + 1024;
+        if (hipHostMalloc(&h_q_, sizeof(float) * 2 * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_q_ = nullptr; return nullptr; }
+        if (hipHostMalloc(&h_val_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_val_ = nullptr; return nullptr; }
+        if (hipHostMalloc(&h_var_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_var_ = nullptr; return nullptr; }
+        cap_hq_ = cap;
+    }
+    return h_q_;
+}
+
+int ObsGPDevice::query_staged(int nq, hipStream_t s) {
+    if (!trained_) return GPIS_ERR_STATE;
+    if (nq <= 0) return GPIS_OK;
+    if (nq > cap_hq_ || !h_q_ || !h_val_ || !h_var_) return GPIS_ERR_STATE;
+    int rc = ensure_q(nq);
+    if (rc) return rc;
+    const int per = (view_.mode == 2) ? 2 : 1;
+    GPIS_HIP(hipMemcpyAsync(d_q_, h_q_, sizeof(float) * per * (size_t)nq, hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemsetAsync(d_val_, 0, sizeof(float) * (size_t)nq, s));
+    obsgp_launch_query(view_, d_q_, nq, d_val_, d_var_, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipMemcpyAsync(h_val_, d_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipMemcpyAsync(h_var_, d_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
     return GPIS_OK;
 }

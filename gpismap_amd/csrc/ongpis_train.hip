@@ -250,6 +250,9 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
 #ifndef K3_T1_NT
 #define K3_T1_NT 3      // tiles per wavefront and round, one-wavefront tier (K <= 256)
 #endif
+#ifndef K3_T1_NW
+#define K3_T1_NW 1      // wavefronts per cluster in the small tier
+#endif
 #ifndef K3_T1_MINW
 #define K3_T1_MINW 2    // wavefronts per SIMD the one-wavefront tier is compiled for
 #endif
@@ -851,7 +854,7 @@ void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s) {
     // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small
     // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
-    if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<K3_T1_NT, 1>), dim3(njobs), dim3(64), 0, s, d_models, d_jobs);
+    if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<K3_T1_NT, K3_T1_NW>), dim3(njobs), dim3(64 * K3_T1_NW), 0, s, d_models, d_jobs);
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 

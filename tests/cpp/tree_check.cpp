@@ -94,6 +94,20 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
             for (size_t i = 0; same && i < fr.size(); ++i)
                 for (int d = 0; d < DIM; ++d) same = same && ft.pts[fr[i]].pos[d] == orr[i]->pos[d];
             if (!same) { fprintf(stderr, "op %d range query mismatch (%zu / %zu)\n", it, fr.size(), orr.size()); ++bad; }
+            // cluster-cell query, with and without distances (octree.cpp:829-893)
+            for (int with_sq = 0; with_sq < 2; ++with_sq) {
+                std::vector<int> fc;
+                std::vector<float> fsq, osq;
+                ft.query_clusters(ft.root, c, h, fc, with_sq ? &fsq : nullptr);
+                std::vector<orc::Tree<DIM>*> oc;
+                ot->queryClusters(orc::Box<DIM>(c, h), oc, with_sq ? &osq : nullptr);
+                bool ok = fc.size() == oc.size() && fsq.size() == osq.size();
+                for (size_t i = 0; ok && i < fc.size(); ++i) {
+                    for (int d = 0; d < DIM; ++d) ok = ok && ft.nodes[fc[i]].c[d] == oc[i]->box.c[d];
+                    if (with_sq) ok = ok && fsq[i] == osq[i];
+                }
+                if (!ok) { fprintf(stderr, "op %d cluster query mismatch (%zu / %zu)\n", it, fc.size(), oc.size()); ++bad; }
+            }
         }
         if (it % 257 == 0 || it == nops - 1) {
             std::vector<int> fa;
