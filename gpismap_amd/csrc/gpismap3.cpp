@@ -410,6 +410,7 @@ void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, c
 // ------------------------------------------------------------ updateMapPoints ----
 void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
     if (!has_tree || !gpo_created) return;
+    UpdLap ulap;
     std::vector<int> oc;
     tree.query_clusters(tree.root, pose_tr, range_obs_max, oc, nullptr);
     if (oc.empty()) return;
@@ -443,7 +444,9 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
     for (int c : sel) tree.all_points(c, ids);
     std::vector<Stage2> st;
     std::vector<float> pval, pvar;
+    ulap("reEvalPoints: select");
     reeval_batch(ids, st, pval, pvar);
+    ulap("reEvalPoints: K2 batches");
     std::vector<int> slot(tree.pts.size(), -1);
     for (size_t i = 0; i < ids.size(); ++i) slot[ids[i]] = (int)i;
 
@@ -468,6 +471,7 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
             }
         }
     }
+    ulap("reEvalPoints: apply");
 }
 
 // ------------------------------------------------------------------ evalPoints ----
