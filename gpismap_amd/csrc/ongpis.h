@@ -121,7 +121,9 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup, sync = 2 ints per job (zeroed)
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, hipStream_t s);
 // K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nshort, hipStream_t s);
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, hipStream_t s);
+int ongpis_inverse_short_rows();
+int ongpis_inverse_short_waves();
 
 struct EvalArgs {
     const ClusterModel* models;

@@ -236,18 +236,29 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     constexpr int kLongCol = 24;
     const int gbeg[4] = {0, ncoop, n0, nj};
     std::vector<int> work;
-    int wl_off[3], wl_long[3], wl_short[3];
+    int wl_off[3], wl_long[3], wl_mid[3], wl_short[3];
+    const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
+    const int kRegWaves = ongpis_inverse_short_waves();
     for (int grp = 0; grp < 3; ++grp) {
-        std::vector<int> wlong, wshort;
+        std::vector<int> wlong, wmid, wshort;
         for (int j = gbeg[grp]; j < gbeg[grp + 1]; ++j) {
             const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+            // register path only for clusters whose columns are ALL short (a third launch per group would serialise
+            // behind the other two for nothing: the short columns of a large cluster are a few percent of its work)
+            const bool reg_cluster = nbj <= kRegCol;
             for (int c = 0; c < nbj; ++c) {
-                std::vector<int>& w = (nbj - c > kLongCol) ? wlong : wshort;
-                w.push_back(j); w.push_back(c);
+                if (!reg_cluster) {
+                    std::vector<int>& w = (nbj - c > kLongCol) ? wlong : wmid;
+                    w.push_back(j); w.push_back(c);
+                } else if ((c - std::max(0, nbj - kRegCol)) % kRegWaves == 0) {   // one entry per kRegWaves adjacent short columns
+                    wshort.push_back(j); wshort.push_back(c);
+                }
             }
         }
-        wl_off[grp] = (int)work.size(); wl_long[grp] = (int)wlong.size() / 2; wl_short[grp] = (int)wshort.size() / 2;
+        wl_off[grp] = (int)work.size(); wl_long[grp] = (int)wlong.size() / 2; wl_mid[grp] = (int)wmid.size() / 2;
+        wl_short[grp] = (int)wshort.size() / 2;
         work.insert(work.end(), wlong.begin(), wlong.end());
+        work.insert(work.end(), wmid.begin(), wmid.end());
         work.insert(work.end(), wshort.begin(), wshort.end());
     }
     if ((int)work.size() > cap_work_) {
@@ -293,7 +304,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), gs[0]);
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
-        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_short[grp], gs[grp]);
+        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], gs[grp]);
         if (grp == 1) { GPIS_HIP(hipEventRecord(evj3_, s3_)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
         if (grp == 2) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     }

@@ -719,19 +719,24 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 // the 8 wavefronts of a workgroup round-robin; row b still needs every earlier row of the column, so the wavefronts run as
 // a software pipeline -- each accumulates its row over the rows already published (LDS counter `rowdone`, tiles travel
 // through Zt in L2) and waits only for the last few.  The chain of a row is unchanged (ascending p, k): same bits.
-template <int NWI>
-__global__ __launch_bounds__(64 * NWI) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
+constexpr int kShortRows = 8;   // K3b: columns with at most this many block rows keep their transposed tiles in registers
+constexpr int kShortWaves = 8;  // ... and are run kShortWaves adjacent columns per workgroup (one wavefront each): the columns
+                                // of a cluster read the same Lt tiles at about the same time, so the CU's L1 serves the repeats
+template <int NWI, bool REGZ>
+__global__ __launch_bounds__(64 * (REGZ ? kShortWaves : NWI), REGZ ? 3 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
                                                                const int* __restrict__ d_jobs, const int* __restrict__ work) {
-    __shared__ __attribute__((aligned(16))) float Tall[NWI][32 * 36];
+    __shared__ __attribute__((aligned(16))) float Tall[REGZ ? kShortWaves : NWI][32 * 36];
     __shared__ int rowdone_s;
     typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;
     lds_flag_ptr rowdone = (lds_flag_ptr)&rowdone_s;
     const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* T = Tall[wave];
-    const int job = work[2 * blockIdx.x], c = work[2 * blockIdx.x + 1];
+    const int job = work[2 * blockIdx.x];
+    const int c = work[2 * blockIdx.x + 1] + (REGZ ? wave : 0);   // REGZ: the entry names the first of kShortWaves columns
     const ClusterModel m = models[JOB_MODEL(job)];
     const int K = m.K, nb = m.nb, nbx = m.ld / 32;
+    if (REGZ && c >= nb) return;
     const int ntl = nbx * (nbx + 1) / 2;
     const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
@@ -795,6 +800,76 @@ __global__ __launch_bounds__(64 * NWI) void ongpis_inv_kernel(const ClusterModel
         for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], sacc[kk], v, 0, 0, 0);
         return v;
     };
+    // Short columns (at most kShortRows block rows below the diagonal, i.e. every column of a K <= 256 cluster and the
+    // last columns of any cluster): the transposed tiles (X_pc)^T stay in REGISTERS as the B operands of the later rows
+    // instead of going through Zt -- no Zt stores, no reads of them back, and the Lt tiles of a row can be fetched ahead
+    // of the chain.  Same operands, same order: bit-identical to the Zt path.
+    if (REGZ && NWI == 1 && nb - c <= kShortRows) {
+        float zr[kShortRows][16];     // zr[kShortRows - 1] is never used as an operand (its row is the last)
+        auto emit_keep = [&](const f32x16& x, int b, float (&zk)[16]) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) T[rowmap_t(r, h) * 36 + l31] = x[r];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float4* xt = reinterpret_cast<float4*>(m.Xt + (size_t)tri_index(b, c) * 1024);
+            const bool mean_row = (32 * b + l31 == K);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4 q;
+                float* qa = reinterpret_cast<float*>(&q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 2 * (4 * g + j) + h;
+                    float v = T[l31 * 36 + k];
+                    if (mean_row) { const int col = 32 * c + k; v = (col < K) ? g_alpha[col] : 0.f; }
+                    qa[j] = v;
+                    zk[4 * g + j] = T[k * 36 + l31];               // (X_bc)^T[l31][k]: the B operand of the later rows
+                }
+                xt[g * 64 + lane] = q;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        const int rows = nb - c;
+        {
+            f32x16 e;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) e[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
+            emit_keep(times_inverse(e, c), c, zr[0]);
+        }
+#pragma unroll
+        for (int i = 1; i < kShortRows; ++i) {
+            if (i < rows) {   // wave-uniform
+                const int b = c + i;
+                f32x16 sacc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+                // the row's operands do not depend on the chain: the next tile (and finally the inverted diagonal block) is in
+                // flight while the current one is multiplied
+                float av[2][16];
+                load_tile(av[0], Lrs, b, c);
+#pragma unroll
+                for (int pi = 0; pi < i; ++pi) {
+                    if (pi + 1 < i) load_tile(av[(pi + 1) & 1], Lrs, b, c + pi + 1);
+                    else load_tile(av[(pi + 1) & 1], Lrs, b, b);
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pi & 1][kk], zr[pi][kk], sacc, 0, 0, 0);
+                }
+                f32x16 v;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = 0.f;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i & 1][kk], sacc[kk], v, 0, 0, 0);
+                emit_keep(v, b, zr[i]);
+            }
+        }
+        if (nbx > nb) {
+            f32x16 z;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            emit_keep(z, nb, zr[kShortRows - 1]);
+        }
+        return;
+    }
     if (wave == 0) {   // diagonal tile: inv(L_cc) times the identity
         f32x16 e;
 #pragma unroll
@@ -862,10 +937,14 @@ void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, co
     if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync);
 }
 
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nshort, hipStream_t s) {
-    // the work list starts with the long columns (8 cooperating wavefronts each), the rest take one wavefront per column
-    if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work);
-    if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1>), dim3(nshort), dim3(64), 0, s, d_models, d_jobs, d_work + 2 * nlong);
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, hipStream_t s) {
+    // the work list starts with the long columns (8 cooperating wavefronts each), then the columns that take one wavefront
+    // and exchange their transposed tiles through Zt, then the columns of at most kShortRows rows (tiles kept in registers)
+    if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8, false>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work);
+    if (nmid > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, false>), dim3(nmid), dim3(64), 0, s, d_models, d_jobs, d_work + 2 * nlong);
+    if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, true>), dim3(nshort), dim3(64 * kShortWaves), 0, s, d_models, d_jobs, d_work + 2 * (nlong + nmid));
 }
+int ongpis_inverse_short_rows() { return kShortRows; }
+int ongpis_inverse_short_waves() { return kShortWaves; }
 
 }  // namespace gpis
