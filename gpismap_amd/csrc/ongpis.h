@@ -124,6 +124,7 @@ void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, co
 void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, hipStream_t s);
 int ongpis_inverse_short_rows();
 int ongpis_inverse_short_waves();
+int ongpis_inverse_mid_waves();
 
 struct EvalArgs {
     const ClusterModel* models;

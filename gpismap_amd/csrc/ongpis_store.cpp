@@ -238,7 +238,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     std::vector<int> work;
     int wl_off[3], wl_long[3], wl_mid[3], wl_short[3];
     const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
-    const int kRegWaves = ongpis_inverse_short_waves();
+    const int kRegWaves = ongpis_inverse_short_waves(), kMidWaves = ongpis_inverse_mid_waves();
     for (int grp = 0; grp < 3; ++grp) {
         std::vector<int> wlong, wmid, wshort;
         for (int j = gbeg[grp]; j < gbeg[grp + 1]; ++j) {
@@ -248,8 +248,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
             const bool reg_cluster = nbj <= kRegCol;
             for (int c = 0; c < nbj; ++c) {
                 if (!reg_cluster) {
-                    std::vector<int>& w = (nbj - c > kLongCol) ? wlong : wmid;
-                    w.push_back(j); w.push_back(c);
+                    if (nbj - c > kLongCol) { wlong.push_back(j); wlong.push_back(c); }
+                    else if ((c - std::max(0, nbj - kLongCol)) % kMidWaves == 0) { wmid.push_back(j); wmid.push_back(c); }   // first of kMidWaves columns
                 } else if ((c - std::max(0, nbj - kRegCol)) % kRegWaves == 0) {   // one entry per kRegWaves adjacent short columns
                     wshort.push_back(j); wshort.push_back(c);
                 }

@@ -722,21 +722,25 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 constexpr int kShortRows = 8;   // K3b: columns with at most this many block rows keep their transposed tiles in registers
 constexpr int kShortWaves = 8;  // ... and are run kShortWaves adjacent columns per workgroup (one wavefront each): the columns
                                 // of a cluster read the same Lt tiles at about the same time, so the CU's L1 serves the repeats
+constexpr int kMidWaves = 8;    // the one-wavefront columns of the larger clusters are grouped the same way
+// NWI = 8: one long column per workgroup, 8 pipelined wavefronts.  NWI = 1: one wavefront per column, kMidWaves (REGZ:
+// kShortWaves) adjacent columns of one cluster per workgroup; the work entry names the first of them.
 template <int NWI, bool REGZ>
-__global__ __launch_bounds__(64 * (REGZ ? kShortWaves : NWI), REGZ ? 3 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
+__global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)), REGZ ? 3 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
                                                                const int* __restrict__ d_jobs, const int* __restrict__ work) {
-    __shared__ __attribute__((aligned(16))) float Tall[REGZ ? kShortWaves : NWI][32 * 36];
+    __shared__ __attribute__((aligned(16))) float Tall[REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)][32 * 36];
     __shared__ int rowdone_s;
     typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;
     lds_flag_ptr rowdone = (lds_flag_ptr)&rowdone_s;
     const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* T = Tall[wave];
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* T = Tall[wave_id];
+    const int wave = (NWI == 1) ? 0 : wave_id;                     // position inside the column's team
     const int job = work[2 * blockIdx.x];
-    const int c = work[2 * blockIdx.x + 1] + (REGZ ? wave : 0);   // REGZ: the entry names the first of kShortWaves columns
+    const int c = work[2 * blockIdx.x + 1] + (NWI == 1 ? wave_id : 0);
     const ClusterModel m = models[JOB_MODEL(job)];
     const int K = m.K, nb = m.nb, nbx = m.ld / 32;
-    if (REGZ && c >= nb) return;
+    if (NWI == 1 && c >= nb) return;
     const int ntl = nbx * (nbx + 1) / 2;
     const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
@@ -804,7 +808,7 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : NWI), REGZ ? 3 : 1) void
     // last columns of any cluster): the transposed tiles (X_pc)^T stay in REGISTERS as the B operands of the later rows
     // instead of going through Zt -- no Zt stores, no reads of them back, and the Lt tiles of a row can be fetched ahead
     // of the chain.  Same operands, same order: bit-identical to the Zt path.
-    if (REGZ && NWI == 1 && nb - c <= kShortRows) {
+    if constexpr (REGZ) {   // (the work list only sends columns with nb - c <= kShortRows here)
         float zr[kShortRows][16];     // zr[kShortRows - 1] is never used as an operand (its row is the last)
         auto emit_keep = [&](const f32x16& x, int b, float (&zk)[16]) {
 #pragma unroll
@@ -891,18 +895,26 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : NWI), REGZ ? 3 : 1) void
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 pe = min(avail, b - 1);
             }
-            float av[2][16], zb[2][16];
+            // three operand stages: two tile pairs are in flight while the third is multiplied (the loop is latency-bound on
+            // the tile loads; the registers are free up to 168)
+            float av[3][16], zb[3][16];
             load_tile(av[0], Lrs, b, p);
             load_tile(zb[0], Zrs, p, c);
+            if (p + 1 <= pe) { load_tile(av[1], Lrs, b, p + 1); load_tile(zb[1], Zrs, p + 1, c); }
 #pragma unroll 1
-            for (int q = p; q <= pe; q += 2) {
-                if (q + 1 <= pe) { load_tile(av[1], Lrs, b, q + 1); load_tile(zb[1], Zrs, q + 1, c); }
+            for (int q = p; q <= pe; q += 3) {
+                if (q + 2 <= pe) { load_tile(av[2], Lrs, b, q + 2); load_tile(zb[2], Zrs, q + 2, c); }
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0][kk], zb[0][kk], sacc, 0, 0, 0);
                 if (q + 1 <= pe) {
-                    if (q + 2 <= pe) { load_tile(av[0], Lrs, b, q + 2); load_tile(zb[0], Zrs, q + 2, c); }
+                    if (q + 3 <= pe) { load_tile(av[0], Lrs, b, q + 3); load_tile(zb[0], Zrs, q + 3, c); }
 #pragma unroll
                     for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1][kk], zb[1][kk], sacc, 0, 0, 0);
+                }
+                if (q + 2 <= pe) {
+                    if (q + 4 <= pe) { load_tile(av[1], Lrs, b, q + 4); load_tile(zb[1], Zrs, q + 4, c); }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[2][kk], zb[2][kk], sacc, 0, 0, 0);
                 }
             }
             p = pe + 1;
@@ -941,10 +953,11 @@ void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, cons
     // the work list starts with the long columns (8 cooperating wavefronts each), then the columns that take one wavefront
     // and exchange their transposed tiles through Zt, then the columns of at most kShortRows rows (tiles kept in registers)
     if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8, false>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work);
-    if (nmid > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, false>), dim3(nmid), dim3(64), 0, s, d_models, d_jobs, d_work + 2 * nlong);
+    if (nmid > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, false>), dim3(nmid), dim3(64 * kMidWaves), 0, s, d_models, d_jobs, d_work + 2 * nlong);
     if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, true>), dim3(nshort), dim3(64 * kShortWaves), 0, s, d_models, d_jobs, d_work + 2 * (nlong + nmid));
 }
 int ongpis_inverse_short_rows() { return kShortRows; }
 int ongpis_inverse_short_waves() { return kShortWaves; }
+int ongpis_inverse_mid_waves() { return kMidWaves; }
 
 }  // namespace gpis
