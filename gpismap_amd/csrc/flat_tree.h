@@ -72,9 +72,13 @@ public:
     std::vector<int> pending_free_pts;  // ids freed during the current update (not reused until recycle())
     std::vector<int> released_models;  // model slots of pruned cluster cells (owner drains this)
     int root = -1;
+    // Last cluster-level cell a point walk went through: consecutive pixels / map points mostly fall into the same cell,
+    // and a walk that starts there gives the same answer as one from the root whenever the point lies inside the cell by
+    // more than the rounding of the boxes (every ancestor then contains it and is an inner node without a point of its own).
+    mutable int last_cell = -1;
 
     bool empty() const { return root < 0; }
-    void clear() { nodes.clear(); pts.clear(); free_nodes.clear(); free_pts.clear(); pending_free_pts.clear(); released_models.clear(); root = -1; }
+    void clear() { nodes.clear(); pts.clear(); free_nodes.clear(); free_pts.clear(); pending_free_pts.clear(); released_models.clear(); root = -1; last_cell = -1; }
     // Point ids freed during an update are only recycled at the next one, so an id names one
     // point object for the whole update (the batched ObsGP results are keyed by id).
     void recycle() { free_pts.insert(free_pts.end(), pending_free_pts.begin(), pending_free_pts.end()); pending_free_pts.clear(); }
@@ -99,6 +103,21 @@ public:
     bool is_root(int n) const { return nodes[n].par < 0; }
     int get_root(int n) const { while (nodes[n].par >= 0) n = nodes[n].par; return n; }
     bool empty_leaf(int n) const { return nodes[n].leaf && nodes[n].pt < 0; }
+
+    // Where a walk for point p may start: the cached cell if p is well inside it, else the root.
+    int walk_start(const float* p) const {
+        const int n = last_cell;
+        if (n < 0 || !nodes[n].alive) return root;
+        const TNode& t = nodes[n];
+        for (int d = 0; d < DIM; ++d) {
+            const float tol = 1e-5f * (std::fabs(t.c[d]) + t.h);
+            if (!(p[d] > t.lo[d] + tol && p[d] < t.hi[d] - tol)) return root;
+        }
+        return n;
+    }
+    bool is_not_new_cached(const float* p) const { return is_not_new(walk_start(p), p); }
+    template <class S>
+    bool insert_cached(int pid, S* quads) { return insert(walk_start(pts[pid].pos), pid, quads); }
 
     // octree.cpp:214-293 / :295-411.  quads == nullptr selects the set-less variant.
     template <class S>
@@ -147,6 +166,7 @@ public:
     bool is_not_new(int n, const float* p) const {  // octree.cpp:431-460
         if (!contains(n, p)) return false;
         for (;;) {
+            if (at_cluster(n)) last_cell = n;
             if (empty_leaf(n)) return false;
             if (nodes[n].pt >= 0 && sqdist(pts[nodes[n].pt].pos, p) < prm.min_half_sq) return true;
             if (nodes[n].leaf) return false;
@@ -287,6 +307,7 @@ private:
         if (t.pt >= 0) drop_point(t.pt);
         if (t.model >= 0) released_models.push_back(t.model);
         nodes[n].alive = false; nodes[n].model = -1; nodes[n].pt = -1;
+        if (n == last_cell) last_cell = -1;
         free_nodes.push_back(n);
     }
     void child_center(int n, int i, float l, float* c) const {
@@ -328,6 +349,7 @@ private:
             nodes[p].ch[slot] = n;
         }  // else: reference quirk -- a childless parent centred at the origin; the old tree is orphaned
         nodes[n].par = p;
+        last_cell = -1;   // the tree above the cached cell changed (and may have been orphaned: see the quirk above)
         return insert(p, pid, (Set*)nullptr);
     }
     void query_range_rec(int n, const float* c, float hsq, const float* lo, const float* hi, std::vector<int>& out) const {

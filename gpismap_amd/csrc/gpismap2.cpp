@@ -141,8 +141,8 @@ bool GPisMap::Impl::preproData(const float* datax, const float* dataf, int N, co
 
 int GPisMap::Impl::try_insert(int pid, T2::InsSet& ins) {  // GPisMap.cpp:433-443 / :497-507
     bool ok_ = false;
-    if (!tree.is_not_new(tree.root, tree.pts[pid].pos)) {
-        ok_ = tree.insert(tree.root, pid, &ins);
+    if (!tree.is_not_new_cached(tree.pts[pid].pos)) {
+        ok_ = tree.insert_cached(pid, &ins);
         if (ok_ && !tree.is_root(tree.root)) tree.root = tree.get_root(tree.root);
     }
     if (!ok_) { tree.drop_point(pid); return 0; }

@@ -224,8 +224,8 @@ bool GPisMap3::Impl::regressObs() {  // :239-256 -> K1
 // reference), 0 when it was not stored (the point object is released).
 int GPisMap3::Impl::try_insert(int pid, T3::InsSet& ins) {
     bool ok_ = false;
-    if (!tree.is_not_new(tree.root, tree.pts[pid].pos)) {
-        ok_ = tree.insert(tree.root, pid, &ins);
+    if (!tree.is_not_new_cached(tree.pts[pid].pos)) {
+        ok_ = tree.insert_cached(pid, &ins);
         if (ok_ && !tree.is_root(tree.root)) tree.root = tree.get_root(tree.root);
     }
     if (!ok_) { tree.drop_point(pid); return 0; }

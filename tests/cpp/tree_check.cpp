@@ -30,12 +30,17 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
     std::vector<std::vector<float>> live;
     const float cell = 2.f * fp.cluster_half;
     int bad = 0, inserted = 0, removed = 0, onplane = 0;
+    float prev[3] = {0, 0, 0};
+    bool have_prev = false;
     for (int it = 0; it < nops && !bad; ++it) {
         int kind = rng() % 10;
         if (kind < 7 || live.empty()) {
             float p[3] = {0, 0, 0};
             int mode = rng() % 8;
             for (int d = 0; d < DIM; ++d) p[d] = spread * U(rng);
+            if (mode >= 5 && have_prev) {        // a neighbour of the previous candidate (scan-line coherence: exercises the cell cache)
+                for (int d = 0; d < DIM; ++d) p[d] = prev[d] + 0.3f * cell * U(rng);
+            }
             if (mode == 0 && !live.empty()) {  // near-duplicate of a stored point
                 const auto& q = live[rng() % live.size()];
                 for (int d = 0; d < DIM; ++d) p[d] = q[d] + 0.7f * fp.min_half * U(rng);
@@ -46,12 +51,16 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
                 int d = rng() % DIM;
                 p[d] = std::nextafterf(cell * (float)((int)(p[d] / cell)), (rng() & 1) ? 1e9f : -1e9f);
             }
+            for (int d = 0; d < DIM; ++d) prev[d] = p[d];
+            have_prev = true;
             // the product's try_insert
             int pid = ft.new_point(p);
             typename FT::InsSet ins;
-            bool f_notnew = ft.is_not_new(ft.root, p), f_ok = false;
+            // (the walks start at the cached cluster cell when the point is well inside it -- as the product's try_insert does)
+            bool f_notnew = ft.is_not_new_cached(p), f_ok = false;
+            if (f_notnew != ft.is_not_new(ft.root, p)) { fprintf(stderr, "op %d: cached and root walks disagree\n", it); ++bad; }
             if (!f_notnew) {
-                f_ok = ft.insert(ft.root, pid, &ins);
+                f_ok = ft.insert_cached(pid, &ins);
                 if (f_ok && !ft.is_root(ft.root)) ft.root = ft.get_root(ft.root);
             }
             if (!f_ok) ft.drop_point(pid);
