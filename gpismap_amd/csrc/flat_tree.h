@@ -218,6 +218,32 @@ public:
         query_range_rec(n, c, h * h, lo, hi, out);
     }
 
+    // Range queries of a batch (updateGPs asks one per cluster, radii overlapping 27 cells each): the points of a cell are
+    // listed once (in traversal order) and every query filters the lists of the cells its box touches, visited in
+    // traversal order too -- the same points in the same order as query_range(), without walking the subtrees again.
+    // (Leaves above the cluster level hold no points, so the cell walk misses nothing.)  Valid while the tree is not modified.
+    struct CellLists {
+        std::vector<int> begin, end;   // by node id; begin < 0: not listed yet
+        std::vector<int> pts, cells;
+        void reset(size_t nnodes) { begin.assign(nnodes, -1); end.assign(nnodes, -1); pts.clear(); }
+    };
+    void query_range_cells(const float* c, float h, CellLists& cl, std::vector<int>& out) const {
+        cl.cells.clear();
+        query_clusters(root, c, h, cl.cells, nullptr);
+        const float hsq = h * h;
+        for (int cell : cl.cells) {
+            if (cl.begin[cell] < 0) {
+                cl.begin[cell] = (int)cl.pts.size();
+                all_points(cell, cl.pts);
+                cl.end[cell] = (int)cl.pts.size();
+            }
+            for (int i = cl.begin[cell]; i < cl.end[cell]; ++i) {
+                const int pid = cl.pts[i];
+                if (sqdist(pts[pid].pos, c) < hsq) out.push_back(pid);
+            }
+        }
+    }
+
     void all_points(int n, std::vector<int>& out) const {  // octree.cpp:806-827
         if (empty_leaf(n)) return;
         if (nodes[n].leaf) { out.push_back(nodes[n].pt); return; }

@@ -448,9 +448,11 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
         std::sort(todo.begin(), todo.end());
         std::vector<TrainJob> jobs;
         std::vector<int> ids, res;
+        T2::CellLists cell_lists;   // the points of every touched cell listed once for the whole batch (flat_tree.h)
+        cell_lists.reset(tree.nodes.size());
         for (int c : todo) {
             res.clear();
-            tree.query_range(tree.root, tree.nodes[c].c, (float)((double)tree.nodes[c].h * 4.0), res);
+            tree.query_range_cells(tree.nodes[c].c, (float)((double)tree.nodes[c].h * 4.0), cell_lists, res);
             if (res.empty()) continue;
             int ng = 0;
             for (int pid : res) {

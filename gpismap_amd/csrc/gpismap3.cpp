@@ -575,9 +575,11 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         std::sort(todo.begin(), todo.end());
         std::vector<TrainJob> jobs;
         std::vector<int> ids, res;
+        T3::CellLists cell_lists;   // the points of every touched cell listed once for the whole batch (flat_tree.h)
+        cell_lists.reset(tree.nodes.size());
         for (int c : todo) {
             res.clear();
-            tree.query_range(tree.root, tree.nodes[c].c, tree.nodes[c].h * kRtimes, res);
+            tree.query_range_cells(tree.nodes[c].c, tree.nodes[c].h * kRtimes, cell_lists, res);
             if (res.empty()) continue;
             int ng = 0;
             for (int pid : res) {  // OnGPIS.cpp:122-125

@@ -103,6 +103,16 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
             for (size_t i = 0; same && i < fr.size(); ++i)
                 for (int d = 0; d < DIM; ++d) same = same && ft.pts[fr[i]].pos[d] == orr[i]->pos[d];
             if (!same) { fprintf(stderr, "op %d range query mismatch (%zu / %zu)\n", it, fr.size(), orr.size()); ++bad; }
+            // the batched form updateGPs uses: cell lists + filter
+            {
+                typename FT::CellLists cl;
+                cl.reset(ft.nodes.size());
+                for (int rep = 0; rep < 2; ++rep) {   // second pass: the lists are reused
+                    std::vector<int> fr2;
+                    ft.query_range_cells(c, h, cl, fr2);
+                    if (fr2 != fr) { fprintf(stderr, "op %d cell-list range query mismatch (%zu / %zu)\n", it, fr2.size(), fr.size()); ++bad; }
+                }
+            }
             // cluster-cell query, with and without distances (octree.cpp:829-893)
             for (int with_sq = 0; with_sq < 2; ++with_sq) {
                 std::vector<int> fc;
