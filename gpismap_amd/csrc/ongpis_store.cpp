@@ -206,13 +206,24 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
     // cooperative group: G workgroups ~ nb^2 (work nb^3 over a critical path of nb steps), one workgroup per CU, at most
     // kCoopMaxWG in the launch so that all of them are resident at once
-    constexpr int kCoopMinNb = 40, kCoopMaxWG = 240;   // below ~40 block rows one workgroup per cluster is faster (measured)
+    // Measured on the synthetic frames (GPIS_K3_TUNE builds read these from the environment): below ~32 block rows one
+    // workgroup per cluster is faster; few workgroups per cluster (so that MANY clusters fit the launch) beat many workgroups
+    // for few clusters -- a cooperative cluster is bound by its serial path, and every large cluster left to the
+    // one-workgroup kernel costs more than a small G costs the largest ones.
+    int kCoopMinNb = 32, kCoopMaxWG = 240;
+    int kCoopGDiv = 900, kCoopGMax = 6;
+#ifdef GPIS_K3_TUNE
+    if (const char* e = getenv("K3_MINNB")) kCoopMinNb = atoi(e);
+    if (const char* e = getenv("K3_MAXWG")) kCoopMaxWG = atoi(e);
+    if (const char* e = getenv("K3_GDIV")) kCoopGDiv = atoi(e);
+    if (const char* e = getenv("K3_GMAX")) kCoopGMax = atoi(e);
+#endif
     int ncoop = 0;
     std::vector<int> cwork;
     for (int j = 0; j < n0; ++j) {
         const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
         if (nbj < kCoopMinNb) break;
-        const int G = std::min(16, std::max(2, (nbj * nbj + 150) / 300));
+        const int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
         if ((int)cwork.size() / 3 + G > kCoopMaxWG) break;
         for (int g = 0; g < G; ++g) { cwork.push_back(j); cwork.push_back(g); cwork.push_back(G); }
         ncoop = j + 1;
