@@ -883,6 +883,10 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
     }
     for (int b = c + 1 + wave; b < nb; b += NWI) {
         if (NWI == 1) __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0): this wave's Zt stores are complete before it reads them back
+        // the inverted diagonal block of the row does not depend on the chain: fetched now, used after the last product (it
+        // sat on the critical path of every row: cycle stamps, -DK3B_TRACE history)
+        float ai[16];
+        if (NWI > 1) load_tile(ai, Lrs, b, b);     // (one-wave columns: fetched at use -- the registers buy a third wave per SIMD there)
         f32x16 sacc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
@@ -919,7 +923,15 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
             }
             p = pe + 1;
         }
-        emit(times_inverse(sacc, b), b);
+        {
+            if (NWI == 1) load_tile(ai, Lrs, b, b);
+            f32x16 v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) v = __builtin_amdgcn_mfma_f32_32x32x2f32(ai[kk], sacc[kk], v, 0, 0, 0);
+            emit(v, b);
+        }
         publish(b);
     }
     // K a multiple of 32: row K sits alone in an extra block row (nb = nbx - 1) whose tiles hold only alpha
