@@ -895,7 +895,8 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
             int pe = b - 1;                 // last row usable now
             if (NWI > 1) {
                 int avail = *rowdone;
-                while (avail < p) { __builtin_amdgcn_s_sleep(1); avail = *rowdone; }
+                long spins = 0;   // bounded like the cooperative kernel's waits: a protocol error must not hang the device
+                while (avail < p && ++spins < (1L << 27)) { __builtin_amdgcn_s_sleep(1); avail = *rowdone; }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 pe = min(avail, b - 1);
             }
