@@ -512,6 +512,9 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         const float* pv = &val[(size_t)7 * k];
         const float* pr = &var[(size_t)7 * k];
         if (pr[0] > setting.obs_var_thre) continue;
+        // (the reference allocates the node before IsNotNew and discards it when the test says "not new", GPisMap3.cpp:611-623:
+        // no side effect, so the nine pixels out of ten that end here never take a point object)
+        if (tree.is_not_new_cached(&obs_valid_xyzglobal[3 * (size_t)k])) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
         T3::InsSet ins;
         if (try_insert(pid, ins) != 2) continue;
