@@ -56,6 +56,9 @@ typedef const int __attribute__((address_space(1))) * giptr;
                             // 128 VGPRs: one accumulator tile then lives in scratch (2.8 TB of spill traffic per 256^3 pass) --
                             // F = 5 bench 1379 ms/step with 2 buffers, 1233 ms/step with 1 (107 VGPRs, no scratch)
 #endif
+#ifndef K4_GEN_UNROLL
+#define K4_GEN_UNROLL 2     // queries of a lane generated per trip of the B-tile loop (2: two independent chains hide the double-precision latencies; 4 measured slower)
+#endif
 #ifndef K4_PRIO
 #define K4_PRIO 0            // s_setprio level of a wave while it multiplies (0: none)
 #endif
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
             xp = x4[p];
         }
-#pragma unroll 1
+#pragma unroll K4_GEN_UNROLL
         for (int j = 0; j < 4; ++j) {
             const int q = 8 * qs + 4 * qh + j;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
