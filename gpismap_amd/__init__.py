@@ -91,6 +91,9 @@ def lib():
     L.gpis_ongpis_eval.argtypes = [vp, fp, C.c_int, ip, ip, C.c_int, fp]
     L.gpis_ongpis_last_ms.argtypes = [vp, fp, fp]
     L.gpis_ongpis_set_exp_table.argtypes = [vp, C.c_int]
+    L.gpis_ongpis_kernel_matrix.argtypes = [vp, fp, ip, fp, fp, C.c_int, fp]
+    L.gpis_ongpis_set_keep_factor.argtypes = [vp, C.c_int]
+    L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -324,12 +327,16 @@ class ObsGP:
 class OnGPIS:
     """Kernel-level K6/K3/K4: batched cluster training and prediction."""
 
-    def __init__(self, dim, scale):
+    def __init__(self, dim, scale, keep_factor=False, fused=True):
+        """keep_factor: models of at most 256 rows (trained on chip) also keep L / alpha / gidx for model();
+        fused=False: every cluster takes the separate training kernels."""
         self.L = lib()
         self.dim = dim
         self.h = C.c_void_p(self.L.gpis_ongpis_create(dim, float(scale)))
         if not self.h:
             raise GpisError("gpis_ongpis_create failed (no HIP device?)")
+        _check(self.L.gpis_ongpis_set_keep_factor(self.h, 1 if keep_factor else 0), "gpis_ongpis_set_keep_factor")
+        _check(self.L.gpis_ongpis_set_fused(self.h, 1 if fused else 0), "gpis_ongpis_set_fused")
 
     def close(self):
         if getattr(self, "h", None):
@@ -383,6 +390,16 @@ class OnGPIS:
         _check(self.L.gpis_ongpis_unpack(self.h, C.c_void_p(d_buf_ptr), int(n), int(stride), _p(ids, C.c_int), C.c_void_p(stream)),
                "gpis_ongpis_unpack")
         return ids
+
+    def kernel_matrix(self, x, gidx, sigx, sigg):
+        """Kernel matrix of the build kernel on caller-given arrays (no gather rule): returns K[r, c], lower triangle."""
+        x = np.ascontiguousarray(x, dtype=np.float32); gidx = np.ascontiguousarray(gidx, dtype=np.int32)
+        sigx = np.ascontiguousarray(sigx, dtype=np.float32); sigg = np.ascontiguousarray(sigg, dtype=np.float32)
+        n = gidx.size
+        K = n + self.dim * int((gidx >= 0).sum())
+        out = np.zeros(K * K, dtype=np.float32)
+        _check(self.L.gpis_ongpis_kernel_matrix(self.h, _p(x), _p(gidx, C.c_int), _p(sigx), _p(sigg), n, _p(out)), "gpis_ongpis_kernel_matrix")
+        return out.reshape(K, K).T.copy()
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

@@ -275,6 +275,21 @@ int gpis_ongpis_set_exp_table(void* s, int on) {
     ((OnHandle*)s)->st.use_exp_table = on != 0;
     return GPIS_OK;
 }
+int gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out) {
+    if (!s) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    return h->st.kernel_matrix(x, gidx, sigx, sigg, n, K_out, h->s);
+}
+int gpis_ongpis_set_keep_factor(void* s, int on) {
+    if (!s) return GPIS_ERR_ARG;
+    ((OnHandle*)s)->st.keep_factor = on != 0;
+    return GPIS_OK;
+}
+int gpis_ongpis_set_fused(void* s, int on) {
+    if (!s) return GPIS_ERR_ARG;
+    ((OnHandle*)s)->st.use_fused = on != 0;
+    return GPIS_OK;
+}
 int gpis_ongpis_last_ms(void* s, float* t, float* e) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;

@@ -74,6 +74,10 @@ public:
     // records -> models.  slots_inout[i] < 0: a new slot is created and returned there; else that slot is (re)used.
     // The models are predict-only (no factor, no training scratch).
     int unpack_models(const void* d_buf, int n, size_t stride, int* slots_inout, hipStream_t s);
+    // Kernel matrix only (the separate build kernel on caller-given arrays, no gather rule): x [N][dim], gidx [N] running
+    // gradient index or -1, sigx / sigg [N]; K_out receives the K x K lower triangle, column-major (ld = K).  Parity of
+    // covFnc.cpp:142-256 / :317-402 against committed fixtures.
+    int kernel_matrix(const float* x, const int* gidx, const float* sigx, const float* sigg, int N, float* K_out, hipStream_t s);
     const ClusterModel* model(int slot) const { return (slot >= 0 && slot < (int)models_.size() && live_[slot]) ? &models_[slot] : nullptr; }
     ClusterModel* d_models() { return d_models_; }   // device array mirroring models_
     int sync_models(hipStream_t s);                  // re-upload descriptor table if dirty
@@ -87,9 +91,13 @@ public:
     long long last_eval_flops = 0;
     bool profile = false;
     bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
+    bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
+                                 // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
+    bool use_fused = true;       // false: every cluster takes the separate gather / build / factorise / invert kernels
 
 private:
-    int alloc_model(int slot, int N, int ng, bool predict_only = false);
+    enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2 };
+    int alloc_model(int slot, int N, int ng, int kind = kAllocFull);
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc);
     int dim_;
     float scale_;
@@ -106,10 +114,24 @@ private:
     int* d_work_ = nullptr; int cap_work_ = 0;   // K3b work list (job, block column)
     int* d_cwork_ = nullptr; int cap_cwork_ = 0; // cooperative K3: (job, g, G) per workgroup, then 2 sync ints per job
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
+    int* d_err_ = nullptr;                       // device error word of the training kernels (zeroed per batch)
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipStream_t s2_ = nullptr, s3_ = nullptr;    // side streams: the three size groups of a training batch run beside each other
     hipEvent_t evf_ = nullptr, evj_ = nullptr, evj3_ = nullptr;   // fork / joins
 };
+
+// K6 + K3 + K3b in one launch for clusters of at most 8 block rows (K <= 256), everything on chip: ongpis_fused.hip
+struct FusedTrainArgs {
+    const ClusterModel* models;
+    const int* jobs;        // 4 ints per job: model slot, offset into ids, N, ng
+    const int* ids;         // concatenated point ids
+    const float* pts;       // point mirror [9][cap]
+    int cap;
+    int* err;               // device error word (bit 0: a job the kernel cannot hold was routed to it)
+};
+#define ONGPIS_FUSED_MAX_K 256
+size_t ongpis_fused_lds_bytes(int nb);
+int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hipStream_t s);
 
 // kernels (ongpis_train.hip / ongpis_test.hip)
 size_t packed_model_bytes(int ld, int N);

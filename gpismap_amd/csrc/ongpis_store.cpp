@@ -14,7 +14,7 @@ OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_
 
 OnGPISStore::~OnGPISStore() {
     clear();
-    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_);
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (evf_) (void)hipEventDestroy(evf_);
@@ -53,10 +53,35 @@ void OnGPISStore::release_slot(int s) {
 
 size_t OnGPISStore::device_bytes() const { return pool_bytes(pool_); }
 
-int OnGPISStore::alloc_model(int slot, int N, int ng, bool predict_only) {
+int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
     ClusterModel& m = models_[slot];
     int K = N + dim_ * ng;
     int ld = (int)align_up((size_t)K + 1, 32);
+    int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
+    const size_t szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
+    if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
+    if (kind != kAllocFull) {
+        // what K4 reads (rowinfo, x4, Xt): imported models and models trained by the fused on-chip kernel;
+        // kAllocLeanFactor adds the factor, alpha and the gradient index for parity tests / gpis_ongpis_get_model
+        size_t oR = 0, szR = sizeof(int) * ld;
+        size_t oX = align_up(oR + szR, 256), szX = sizeof(float) * 4 * (size_t)N;
+        size_t oXt = align_up(oX + szX, 256);
+        size_t total = align_up(oXt + szT, 256);
+        size_t oL = 0, oA = 0, oG = 0;
+        if (kind == kAllocLeanFactor) {
+            oL = total; oA = align_up(oL + sizeof(float) * (size_t)ld * ld, 256); oG = align_up(oA + sizeof(float) * ld, 256);
+            total = align_up(oG + sizeof(int) * (size_t)N, 256);
+        }
+        char* base = (char*)pool_alloc(pool_, total);
+        if (!base) return GPIS_ERR_HIP;
+        std::memset(&m, 0, sizeof(ClusterModel));
+        m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
+        m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
+        if (kind == kAllocLeanFactor) { m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.gidx = (int*)(base + oG); }
+        m.base = base;
+        dirty_ = true;
+        return GPIS_OK;
+    }
     size_t oL = 0, szL = sizeof(float) * (size_t)ld * ld;
     size_t oA = align_up(oL + szL, 256), szA = sizeof(float) * ld;
     size_t oX = align_up(oA + szA, 256), szX = sizeof(float) * 4 * (size_t)N;
@@ -64,25 +89,12 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, bool predict_only) {
     size_t oY = align_up(oR + szR, 256), szY = sizeof(float) * ld;
     size_t oS = align_up(oY + szY, 256), szS = sizeof(float) * 2 * (size_t)N;
     size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
-    int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
-    size_t oT = align_up(oG + szG, 256), szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
+    size_t oT = align_up(oG + szG, 256);
     size_t oXt = align_up(oT + szT, 256), oZt = align_up(oXt + szT, 256);   // explicit inverse, re-tiled, and its transposed tiles
     size_t total = align_up(oZt + szT, 256);
-    if (predict_only) {   // imported model: only what K4 reads (rowinfo, x4, Xt)
-        oR = 0; oX = align_up(oR + szR, 256); oXt = align_up(oX + szX, 256);
-        total = align_up(oXt + szT, 256);
-    }
-    if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
     char* base = (char*)pool_alloc(pool_, total);
     if (!base) return GPIS_ERR_HIP;
-    if (predict_only) {
-        std::memset(&m, 0, sizeof(ClusterModel));
-        m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
-        m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
-        m.base = base;
-        dirty_ = true;
-        return GPIS_OK;
-    }
+    std::memset(&m, 0, sizeof(ClusterModel));
     m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
     m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
     m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
@@ -150,7 +162,8 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
             if (!deferred_rc) deferred_rc = GPIS_ERR_LIMIT;
             continue;
         }
-        int rc = alloc_model(tj.model, tj.n, tj.ng);
+        const bool fused = use_fused && K <= ONGPIS_FUSED_MAX_K && tj.n <= 256;
+        int rc = alloc_model(tj.model, tj.n, tj.ng, fused ? (keep_factor ? kAllocLeanFactor : kAllocPredictOnly) : kAllocFull);
         if (rc) {
             ClusterModel& m = models_[tj.model];
             std::memset(&m, 0, sizeof(ClusterModel));   // untrained; slot stays live
@@ -245,7 +258,13 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     // K3b work lists per group: one entry per (job, block column); columns longer than kLongCol rows first (a workgroup
     // of 8 pipelined wavefronts each), the rest one wavefront per column
     constexpr int kLongCol = 24;
-    const int gbeg[4] = {0, ncoop, n0, nj};
+    // clusters of at most ONGPIS_FUSED_MAX_K rows: one fused on-chip launch per size tier (ongpis_fused.hip) instead of
+    // group 2's gather / build / factorise / invert chain
+    const bool fused2 = use_fused;
+    const int nsep = fused2 ? n0 : nj;         // jobs that take the separate kernels
+    int n1 = n0;                               // fused tier boundary: [n0, n1) up to 8 block rows, [n1, nj) up to 5
+    while (fused2 && n1 < nj && (tab[4 * n1 + 2] + dim_ * tab[4 * n1 + 3] + 31) / 32 > 5) ++n1;
+    const int gbeg[4] = {0, ncoop, n0, nsep};
     std::vector<int> work;
     int wl_off[3], wl_long[3], wl_mid[3], wl_short[3];
     const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
@@ -303,11 +322,34 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
     }
-    ongpis_launch_gather(d_models_, d_jobs_, nj, d_ids_, pts_.d, pts_.cap, s);
-    ongpis_launch_buildK(d_models_, d_jobs_, nj, s);
+    if (!d_err_) GPIS_HIP(hipMalloc(&d_err_, sizeof(int) * 4));
+    GPIS_HIP(hipMemsetAsync(d_err_, 0, sizeof(int) * 4, s));
+    if (nsep > 0) {
+        ongpis_launch_gather(d_models_, d_jobs_, nsep, d_ids_, pts_.d, pts_.cap, s);
+        ongpis_launch_buildK(d_models_, d_jobs_, nsep, s);
+    }
     // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream
     GPIS_HIP(hipEventRecord(evf_, s));
     hipStream_t gs[3] = {s, s3_, s2_};
+    if (fused2 && nj > n0) {
+        GPIS_HIP(hipStreamWaitEvent(s2_, evf_, 0));
+        FusedTrainArgs fa;
+        fa.models = d_models_; fa.ids = d_ids_; fa.pts = pts_.d; fa.cap = pts_.cap; fa.err = d_err_;
+        if (n1 > n0) {
+            fa.jobs = d_jobs_ + 4 * n0;
+            const int nbmax = (tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] + 31) / 32;
+            int frc = ongpis_launch_train_fused(fa, n1 - n0, nbmax, s2_);
+            if (frc) return frc;
+        }
+        if (nj > n1) {
+            fa.jobs = d_jobs_ + 4 * n1;
+            const int nbmax = (tab[4 * n1 + 2] + dim_ * tab[4 * n1 + 3] + 31) / 32;
+            int frc = ongpis_launch_train_fused(fa, nj - n1, nbmax, s2_);
+            if (frc) return frc;
+        }
+        GPIS_HIP(hipEventRecord(evj_, s2_));
+        GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
+    }
     for (int grp = 0; grp < 3; ++grp) {
         const int nbeg = gbeg[grp], ncnt = gbeg[grp + 1] - gbeg[grp];
         if (ncnt <= 0) continue;
@@ -321,9 +363,53 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     }
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
+    int h_err[4] = {0, 0, 0, 0};
+    GPIS_HIP(hipMemcpyAsync(h_err, d_err_, sizeof(h_err), hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
     if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
+    if (h_err[0]) {
+        fprintf(stderr, "[gpismap_amd] training kernels reported error word 0x%x: the batch is not usable\n", h_err[0]);
+        return GPIS_ERR_STATE;
+    }
     return deferred_rc;
+}
+
+int OnGPISStore::kernel_matrix(const float* x, const int* gidx, const float* sigx, const float* sigg, int N, float* K_out, hipStream_t s) {
+    if (!x || !gidx || !sigx || !sigg || !K_out || N < 1) return GPIS_ERR_ARG;
+    int ng = 0;
+    for (int k = 0; k < N; ++k) {
+        if (gidx[k] >= 0) { if (gidx[k] != ng) return GPIS_ERR_ARG; ++ng; }
+    }
+    const int slot = new_slot();
+    int rc = alloc_model(slot, N, ng, kAllocFull);
+    if (rc) { release_slot(slot); return rc; }
+    const ClusterModel m = models_[slot];
+    std::vector<float> x4((size_t)4 * N, 0.f), sig((size_t)2 * N), y((size_t)m.ld, 0.f);
+    for (int k = 0; k < N; ++k) {
+        for (int d = 0; d < dim_; ++d) x4[(size_t)4 * k + d] = x[(size_t)dim_ * k + d];
+        sig[k] = sigx[k]; sig[N + k] = sigg[k];
+    }
+    rc = sync_models(s);
+    if (rc) { release_slot(slot); return rc; }
+    const int job[4] = {slot, 0, N, ng};
+    int* d_job = nullptr;
+    GPIS_HIP(hipMalloc(&d_job, sizeof(job)));
+    GPIS_HIP(hipMemcpyAsync(d_job, job, sizeof(job), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(m.x4, x4.data(), sizeof(float) * x4.size(), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(m.sig, sig.data(), sizeof(float) * sig.size(), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(m.gidx, gidx, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(m.y, y.data(), sizeof(float) * y.size(), hipMemcpyHostToDevice, s));
+    ongpis_launch_buildK(d_models_, d_job, 1, s);
+    GPIS_HIP(hipGetLastError());
+    std::vector<float> L((size_t)m.ld * m.ld);
+    GPIS_HIP(hipMemcpyAsync(L.data(), m.L, sizeof(float) * L.size(), hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    (void)hipFree(d_job);
+    const int K = m.K;
+    for (int c = 0; c < K; ++c)
+        for (int r = 0; r < K; ++r) K_out[r + (size_t)c * K] = (r >= c) ? L[r + (size_t)c * m.ld] : 0.f;
+    release_slot(slot);
+    return GPIS_OK;
 }
 
 size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
@@ -366,7 +452,7 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
             return GPIS_ERR_ARG;
         if (slots[i] < 0) slots[i] = new_slot();
         else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return GPIS_ERR_ARG;
-        int rc = alloc_model(slots[i], N, ng, true);
+        int rc = alloc_model(slots[i], N, ng, kAllocPredictOnly);
         if (rc) return rc;
     }
     int rc = sync_models(s);

@@ -164,37 +164,6 @@ __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel*
 // matrix through memory.  The per-element operation order is the ascending-k fmaf chain of
 // dev_common.h: results are bit-identical to the unblocked chain.
 // ---------------------------------------------------------------------------
-// Right-looking factorisation of a full 32 x 32 diagonal block in registers: lane = row (both lane halves carry the same
-// rows), a[k] = column k; pivots and column entries travel by v_readlane.  Element (i, k) takes fmaf(-l_ic, l_kc, .) for c
-// ascending: order (O1).  Entries above the diagonal are scratch values nobody reads.  The square root and the division
-// of the NEXT pivot column are started as soon as that column is updated, ahead of the other columns' updates of the
-// current step: same operations in an order that lets the dependent sqrt/divide chain overlap the broadcasts and fmas
-// (measured: no difference in kernel time on either the stress or the frame workload -- kept as the single shared copy).
-__device__ __forceinline__ void factor32_inreg(float (&a)[32], int row) {
-    float d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[0]), 0)));
-    float lic = a[0] / d;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) {
-        a[c] = (row == c) ? d : lic;
-        const float nl = -lic;
-        float dn = 0.f, licn = 0.f;
-        if (c + 1 < 32) {
-            const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), c + 1));
-            a[c + 1] = fmaf(nl, lk1, a[c + 1]);
-            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c + 1]), c + 1)));
-            licn = a[c + 1] / dn;
-        }
-#pragma unroll
-        for (int k = c + 2; k < 32; ++k) {
-            const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), k));
-            a[k] = fmaf(nl, lkc, a[k]);
-        }
-        d = dn; lic = licn;
-        __builtin_amdgcn_sched_barrier(0);   // keep the broadcast values of one column step together
-    }
-}
-
-__device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 + c; }
 
 // z = row K of the factor -> y ; then alpha = L^-T z, blocked, chain order (O2); finally the padding the blocked solves rely on.
 // Right-looking over block columns c = nb-1 .. 0:  wave 0 solves the 32 x 32 triangle L_cc^T a_c = y_c (lane = unknown, its

@@ -134,6 +134,16 @@ long long gpis_ongpis_packed_bytes(void* s, const int* models, int n);
 int   gpis_ongpis_pack(void* s, const int* models, int n, void* d_buf, long long stride, void* hip_stream);
 int   gpis_ongpis_unpack(void* s, const void* d_buf, int n, long long stride, int* models_inout, void* hip_stream);
 int   gpis_ongpis_set_exp_table(void* s, int on);
+/* Clusters of at most 256 rows are trained by one fused on-chip kernel and keep only what prediction reads
+ * (row table, points, the re-tiled inverse factor).  keep_factor(1) BEFORE training makes such models carry L, alpha
+ * and gidx as well (gpis_ongpis_get_model returns GPIS_ERR_STATE for a model without them); set_fused(0) sends every
+ * cluster through the separate gather / build / factorise / invert kernels (same results, bit for bit). */
+/* kernel matrix only (the build kernel on caller-given arrays, no gather rule): x [n][dim], gidx [n] running gradient
+ * index or -1, sigx / sigg [n]; K_out receives the K x K lower triangle, column-major, K = n + dim * #(gidx >= 0).
+ * reference matern32_sparse_deriv1_3D / _2D (train), covFnc.cpp:142-256 / :317-402 */
+int   gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out);
+int   gpis_ongpis_set_keep_factor(void* s, int on);
+int   gpis_ongpis_set_fused(void* s, int on);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 
 #ifdef __cplusplus

@@ -392,6 +392,7 @@ struct OnGPIS {
     std::vector<float> Linv;   // inverted 32x32 diagonal blocks of L (linalg.hpp, fwd_subst_blocked)
     std::vector<float> X;      // tiled mode: explicit inverse X = L^-1, column-major K x K (lower), see train()
     int mode = ARITH_TILED;    // arithmetic variant the model was trained in: predictions use the same one
+    std::vector<float> tr_pos, tr_grad, tr_val, tr_sx, tr_sg;   // the training set as given (retrain(): same-map comparisons)
 
     OnGPIS(int dim_, float s) : dim(dim_), scale(s), three_over_scale((float)(3.0 / (double)(s * s))) {}
 
@@ -400,6 +401,10 @@ struct OnGPIS {
         trained = false; N = 0;
         if (n <= 0) return;
         N = n;
+        if (pos != tr_pos.data()) {
+            tr_pos.assign(pos, pos + (size_t)dim * n); tr_grad.assign(grad, grad + (size_t)dim * n);
+            tr_val.assign(val, val + n); tr_sx.assign(sx, sx + n); tr_sg.assign(sg, sg + n);
+        }
         x.assign(pos, pos + (size_t)dim * N);
         gidx.assign(N, -1);
         std::vector<float> sigx(sx, sx + N), sigg(sg, sg + N);
@@ -443,6 +448,13 @@ struct OnGPIS {
             }
         }
         trained = true;
+    }
+
+    // Train again on the stored training set in the CURRENT arithmetic mode (linalg.hpp): a map built in one mode can be
+    // re-factorised in another, so that two modes are compared on identical maps and identical training sets.
+    void retrain() {
+        if (tr_val.empty()) return;
+        train(tr_pos.data(), tr_grad.data(), tr_val.data(), tr_sx.data(), tr_sg.data(), (int)tr_val.size());
     }
 
     // Reduction order (O3) of the sum of squares ||V||^2 (tiled mode).  Eigen evaluates it with packet-wise

@@ -88,6 +88,20 @@ public:
         }
     }
 
+    // every trained cluster re-factorised in the current arithmetic mode on its stored training set (gp.hpp retrain)
+    int retrainAll() {
+        if (!t) return 0;
+        float c0[2] = {0, 0};
+        std::vector<T2*> q;
+        t->queryClusters(Box<2>(c0, 1e9f), q, nullptr);
+        parallel_for((int)q.size(), nthreads, [&](int a, int b) {
+            for (int i = a; i < b; ++i) if (q[i]->gp) q[i]->gp->retrain();
+        });
+        int n = 0;
+        for (T2* c : q) if (c->gp && c->gp->trained) ++n;
+        return n;
+    }
+
     std::unique_ptr<ObsGP1D> gpo;
     T2* t = nullptr;
 

@@ -126,6 +126,40 @@ public:
             out.push_back(n->val); out.push_back(n->sigx); out.push_back(n->sigg);
         }
     }
+    // every trained cluster re-factorised in the current arithmetic mode on its stored training set (gp.hpp retrain)
+    int retrainAll() {
+        if (!t) return 0;
+        float c0[3] = {0, 0, 0};
+        std::vector<T3*> q;
+        t->queryClusters(Box<3>(c0, 1e9f), q, nullptr);
+        parallel_for((int)q.size(), nthreads, [&](int a, int b) {
+            for (int i = a; i < b; ++i) if (q[i]->gp) q[i]->gp->retrain();
+        });
+        int n = 0;
+        for (T3* c : q) if (c->gp && c->gp->trained) ++n;
+        return n;
+    }
+    // training set of the i-th trained cluster (traversal order): n x 9 floats pos3 grad3 val sigx sigg; returns n
+    int clusterSamples(int i, float* out9, int cap) {
+        if (!t) return 0;
+        float c0[3] = {0, 0, 0};
+        std::vector<T3*> q;
+        t->queryClusters(Box<3>(c0, 1e9f), q, nullptr);
+        int k = 0;
+        for (T3* c : q) {
+            if (!c->gp || !c->gp->trained) continue;
+            if (k++ != i) continue;
+            const OnGPIS& g = *c->gp;
+            const int n = (int)g.tr_val.size();
+            if (out9 && n <= cap)
+                for (int j = 0; j < n; ++j) {
+                    for (int d = 0; d < 3; ++d) { out9[9 * j + d] = g.tr_pos[3 * j + d]; out9[9 * j + 3 + d] = g.tr_grad[3 * j + d]; }
+                    out9[9 * j + 6] = g.tr_val[j]; out9[9 * j + 7] = g.tr_sx[j]; out9[9 * j + 8] = g.tr_sg[j];
+                }
+            return n;
+        }
+        return 0;
+    }
     int numClusters() {
         if (!t) return 0;
         float c[3] = {0, 0, 0};

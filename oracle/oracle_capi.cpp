@@ -70,6 +70,11 @@ int orc3_get_nodes(void* h, float* out9, int cap) {
     if (out9 && n <= cap) std::memcpy(out9, p.data(), p.size() * sizeof(float));
     return n;
 }
+// same-map comparison of arithmetic modes: re-factorise every trained cluster on its stored training set in the
+// CURRENT mode (orc_set_arith_mode); the map (points, tree, cluster sets) stays what the original mode built
+int orc3_retrain_all(void* h) { return ((GPisMap3*)h)->retrainAll(); }
+int orc2_retrain_all(void* h) { return ((GPisMap2*)h)->retrainAll(); }
+int orc3_cluster_samples(void* h, int i, float* out9, int cap) { return ((GPisMap3*)h)->clusterSamples(i, out9, cap); }
 int orc3_num_clusters(void* h) { return ((GPisMap3*)h)->numClusters(); }
 void orc3_stats(void* h, long* out6) {
     auto& s = ((GPisMap3*)h)->stats;

@@ -57,6 +57,9 @@ def lib():
         L.orc2_get_nodes.argtypes = [C.c_void_p, fp, C.c_int]
         L.orc2_stats.argtypes = [C.c_void_p, C.POINTER(C.c_long)]
         L.orc2_obsgp_sizes.argtypes = [C.c_void_p, ip, C.c_int]
+        L.orc3_retrain_all.argtypes = [C.c_void_p]
+        L.orc3_cluster_samples.argtypes = [C.c_void_p, C.c_int, fp, C.c_int]
+        L.orc2_retrain_all.argtypes = [C.c_void_p]
         L.orc_set_arith_mode.argtypes = [C.c_int]
         L.orc_chol_lower.argtypes = [fp, C.c_int, C.c_int]
         L.orc_fwd_subst.argtypes = [fp, C.c_int, C.c_int, fp, C.c_int, C.c_int]
@@ -177,6 +180,23 @@ class OracleMap3:
     def num_clusters(self):
         return self.L.orc3_num_clusters(self.h)
 
+    def cluster_samples(self, i):
+        """Training set of the i-th trained cluster (traversal order): [n, 9] pos3 grad3 val sigx sigg, or None."""
+        n = self.L.orc3_cluster_samples(self.h, i, None, 0)
+        if n <= 0:
+            return None
+        out = np.zeros((n, 9), dtype=np.float32)
+        self.L.orc3_cluster_samples(self.h, i, _p(out), n)
+        return out
+
+    def retrain_all(self, mode):
+        """Re-factorise every trained cluster on its stored training set in arithmetic `mode`; the map itself (points,
+        tree, cluster sets) is untouched.  Leaves the process-global mode at "tiled".  Returns the clusters retrained."""
+        set_arith_mode(mode)
+        n = self.L.orc3_retrain_all(self.h)
+        set_arith_mode("tiled")
+        return n
+
     def stats(self):
         a = (C.c_long * 6)()
         self.L.orc3_stats(self.h, a)
@@ -227,6 +247,12 @@ class OracleMap2:
         fl = np.zeros(x.shape[0], dtype=np.int32)
         self.L.orc2_test_flags(self.h, _p(x), x.shape[0], _p(fl, C.c_int))
         return fl
+
+    def retrain_all(self, mode):
+        set_arith_mode(mode)
+        n = self.L.orc2_retrain_all(self.h)
+        set_arith_mode("tiled")
+        return n
 
     def nodes(self):
         n = self.L.orc2_get_nodes(self.h, None, 0)

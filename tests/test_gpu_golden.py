@@ -85,7 +85,7 @@ def test_f3_clusters_vs_committed_fixtures():
     for name in ("small", "medium", "large", "2d"):
         nd = z["f3_%s_nodes" % name]; dim = 2 if name == "2d" else 3; scale = 1.2 if dim == 2 else 0.04
         pos = nd[:, :dim]; grad = nd[:, dim:2 * dim]; val = nd[:, 2 * dim]; sx = nd[:, 2 * dim + 1]; sg = nd[:, 2 * dim + 2]
-        st = gpismap_amd.OnGPIS(dim, scale)
+        st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
         n = nd.shape[0]
         models = st.train(soa9(dim, pos, grad, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
         m = st.model(models[0])

@@ -52,7 +52,7 @@ def test_train_and_predict_match_oracle(dim, scale, sizes):
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     # training order inside a cluster is the id order given: shuffle to exercise the gather
     ids = np.concatenate([off[i] + rng.permutation(sizes[i]) for i in range(len(sizes))]).astype(np.int32)
-    st = gpismap_amd.OnGPIS(dim, scale)
+    st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
     models = st.train(soa9(dim, pos, grad, val, sx, sg), off, ids)
     print("train ms", st.last_ms()[0])
     jq, jm, xq_all, ref_all = [], [], [], []
@@ -114,7 +114,7 @@ def test_size_class_boundaries(n):
     dim, scale = 3, 0.04
     rng = np.random.default_rng(1000 + n)
     pos, grad, val, sx, sg = make_cluster(rng, dim, n, scale, frac_nograd=0.0)
-    st = gpismap_amd.OnGPIS(dim, scale)
+    st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
     models = st.train(soa9(dim, pos, grad, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
     o = oracle_lib.ongpis_train(dim, scale, pos, grad, val, sx, sg)
     g = st.model(models[0])
@@ -143,7 +143,7 @@ def test_predict_without_exp_table_is_identical():
     sg = np.concatenate([c[4] for c in clusters])
     off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
     ids = np.arange(off[-1], dtype=np.int32)
-    st = gpismap_amd.OnGPIS(dim, scale)
+    st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
     models = st.train(soa9(dim, pos, grad, val, sx, sg), off, ids)
     nq = 41
     xq = np.concatenate([pos[off[i]:off[i + 1]][rng.integers(0, sizes[i], nq)] + rng.normal(0, 0.3 * scale, (nq, dim))
@@ -164,7 +164,7 @@ def test_large_cluster_beyond_one_row_group():
     rng = np.random.default_rng(3)
     n = 900
     pos, nrm, val, sx, sg = make_cluster(rng, 3, n, 0.04, frac_nograd=0.0)
-    st = gpismap_amd.OnGPIS(3, 0.04)
+    st = gpismap_amd.OnGPIS(3, 0.04, keep_factor=True)
     models = st.train(soa9(3, pos, nrm, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
     m = st.model(models[0])
     assert m["K"] == 3600
@@ -177,3 +177,53 @@ def test_large_cluster_beyond_one_row_group():
     out = st.eval(xq, np.arange(nq, dtype=np.int32), np.full(nq, models[0], dtype=np.int32))
     got = np.concatenate([out[:, :4], out[:, 4:8]], axis=1)
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,scale,sizes", [
+    (3, 0.04, [1, 2, 7, 8, 9, 31, 33, 40, 50, 63, 64]),     # K = 4 N (all with normals): 1 .. 8 block rows, K = 256 included
+    (3, 0.04, [5, 17, 40, 64, 100, 150, 230, 256]),         # mixed gradient flags; N = 256 value-only points -> K = 256
+    (2, 1.2, [3, 26, 60, 85]),
+])
+def test_fused_training_equals_separate_kernels(dim, scale, sizes):
+    """Clusters of at most 256 rows are trained by ONE on-chip kernel (ongpis_fused.hip) that only writes what prediction
+    reads.  Same batch through the fused kernel without the factor (the product configuration), through the fused kernel
+    with the factor kept, and through the separate gather / build / factorise / invert kernels: factor and alpha
+    bit-identical to the oracle, predictions bit-identical across the three."""
+    import gpismap_amd
+    rng = np.random.default_rng(4242 + dim + len(sizes))
+    value_only = sizes[-1] == 256
+    clusters = [make_cluster(rng, dim, n, scale, frac_nograd=(1.0 if (value_only and n == 256) else (0.0 if sizes[0] == 1 else 0.3)))
+                for n in sizes]
+    pos = np.concatenate([c[0] for c in clusters]); grad = np.concatenate([c[1] for c in clusters])
+    val = np.concatenate([c[2] for c in clusters]); sx = np.concatenate([c[3] for c in clusters])
+    sg = np.concatenate([c[4] for c in clusters])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ids = np.concatenate([off[i] + rng.permutation(sizes[i]) for i in range(len(sizes))]).astype(np.int32)
+    P = soa9(dim, pos, grad, val, sx, sg)
+    nq = 21
+    xq = np.concatenate([pos[off[i]:off[i + 1]][rng.integers(0, sizes[i], nq)] + rng.normal(0, 0.3 * scale, (nq, dim))
+                         for i in range(len(sizes))]).astype(np.float32)
+    jq = np.arange(xq.shape[0], dtype=np.int32)
+    outs = []
+    for kw in (dict(), dict(keep_factor=True), dict(fused=False)):
+        st = gpismap_amd.OnGPIS(dim, scale, **kw)
+        models = st.train(P, off, ids)
+        outs.append(st.eval(xq, jq, np.repeat(models, nq).astype(np.int32)).copy())
+        if kw.get("keep_factor"):
+            for ci, n in enumerate(sizes):
+                sel = ids[off[ci]:off[ci + 1]]
+                o = oracle_lib.ongpis_train(dim, scale, pos[sel], grad[sel], val[sel], sx[sel], sg[sel])
+                g = st.model(models[ci])
+                K = o["K"]
+                assert g["K"] == K
+                np.testing.assert_array_equal(g["gidx"], o["gidx"])
+                assert np.array_equal(np.tril(g["L"][:K, :K]).view(np.uint32), np.tril(o["L"]).view(np.uint32)), (n, K)
+                assert np.array_equal(g["alpha"].view(np.uint32), o["alpha"].view(np.uint32)), (n, K)
+                ld = g["ld"]
+                pad = g["L"][K:ld, :]
+                assert np.array_equal(np.tril(pad[:, K:ld]), np.eye(ld - K, dtype=np.float32)) and np.all(pad[:, :K] == 0)
+        elif not kw:
+            with pytest.raises(gpismap_amd.GpisError):     # lean models carry no factor
+                st.model(models[0])
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))

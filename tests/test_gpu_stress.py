@@ -37,7 +37,7 @@ def test_stress_batch_train_and_predict():
     pos, grad, val, sx, sg = make_stress(ncl, rng)
     off = (np.arange(ncl + 1) * 64).astype(np.int32)
     ids = np.arange(ncl * 64, dtype=np.int32)
-    st = gpismap_amd.OnGPIS(3, 0.04)
+    st = gpismap_amd.OnGPIS(3, 0.04, keep_factor=True)
     models = st.train(soa9(3, pos, grad, val, sx, sg), off, ids)
     tr_ms = st.last_ms()[0]
     # 64 queries per cluster, near its points
@@ -78,7 +78,7 @@ def test_stress_full_scale_50k_clusters():
     pos, grad, val, sx, sg = replay.stress_clusters(ncl, rng)
     off = (np.arange(ncl + 1) * 64).astype(np.int32)
     ids = np.arange(ncl * 64, dtype=np.int32)
-    st = gpismap_amd.OnGPIS(3, 0.04)
+    st = gpismap_amd.OnGPIS(3, 0.04, keep_factor=True)
     models = st.train(soa9(3, pos, grad, val, sx, sg), off, ids)
     tr_ms = st.last_ms()[0]
     nq = 64

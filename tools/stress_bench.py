@@ -21,10 +21,14 @@ def main():
     off = (np.arange(ncl + 1) * 64).astype(np.int32)
     ids = np.arange(ncl * 64, dtype=np.int32)
     st = gpismap_amd.OnGPIS(3, 0.04)
-    t0 = time.perf_counter()
-    models = st.train(soa9(3, pos, grad, val, sx, sg), off, ids)
-    wall = (time.perf_counter() - t0) * 1e3
-    tr = st.last_ms()[0]
+    P = soa9(3, pos, grad, val, sx, sg)
+    for rep in range(2):          # second pass: pools warm, kernels loaded
+        t0 = time.perf_counter()
+        models = st.train(P, off, ids)
+        wall = (time.perf_counter() - t0) * 1e3
+        tr = st.last_ms()[0]
+        if rep == 0:
+            print("first pass: device %.1f ms, wall %.0f ms" % (tr, wall))
     K = 256
     print("train: %d clusters K=%d: device %.1f ms (%.2f us/cluster, %.2f TFLOP/s of K^3/3+2K^2), wall incl. allocation %.0f ms"
           % (ncl, K, tr, 1e3 * tr / ncl, ncl * (K ** 3 / 3 + 2 * K * K) / tr / 1e9, wall))
