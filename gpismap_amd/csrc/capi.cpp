@@ -290,6 +290,13 @@ int gpis_ongpis_set_fused(void* s, int on) {
     ((OnHandle*)s)->st.use_fused = on != 0;
     return GPIS_OK;
 }
+int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {
+    if (!s || wait_limit_ms < 0 || wait_limit_ms > 20000) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    h->st.debug_inject = inject;
+    h->st.wait_limit_ticks = wait_limit_ms * 100000;     // 100 MHz device clock
+    return GPIS_OK;
+}
 int gpis_ongpis_last_ms(void* s, float* t, float* e) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;

@@ -93,6 +93,8 @@ public:
     bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
     bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
                                  // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
+    int debug_inject = 0;        // test-only fault injection for the cooperative kernel (ongpis_train.hip, ctl[1])
+    int wait_limit_ticks = 0;    // bound of the in-kernel waits in 100 MHz ticks (0: 2 s)
     bool use_fused = true;       // false: every cluster takes the separate gather / build / factorise / invert kernels
 
 private:
@@ -141,9 +143,12 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup, sync = 2 ints per job (zeroed)
-void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, hipStream_t s);
+// d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
+// wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
+void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
+int ongpis_coop_capacity();
 // K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, hipStream_t s);
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, int* d_ctl, hipStream_t s);
 int ongpis_inverse_short_rows();
 int ongpis_inverse_short_waves();
 int ongpis_inverse_mid_waves();

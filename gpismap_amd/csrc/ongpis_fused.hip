@@ -64,35 +64,50 @@ __device__ __forceinline__ float hi_half(float x) {   // the value of lane 32 + 
 
 typedef volatile int __attribute__((address_space(3))) * lds_flag_t;
 
-// factor32_inreg (tile_solve.h: same operations, same order) in four segments of eight columns: every column is stored
-// column-major into Lc (zeros above the diagonal) right after its division, so that between the segments (workgroup
-// barriers) the panel solves of the other wavefronts consume the columns already final.  (d, lic) carry the pivot and
-// the divided column of the next step across the segments.
-template <int C0>
-__device__ __forceinline__ void factor32_seg(float (&a)[32], int row, int lane, float* Lc, float& d, float& lic) {
-    if (C0 == 0) {
-        d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[0]), 0)));
-        lic = a[0] / d;
-    }
+// Factorisation of a 32 x 32 diagonal tile, same operations in the same order as factor32_inreg (tile_solve.h), in four
+// micro-blocks of eight columns.  The tile stays in ACCUMULATOR layout (t: lane = row, 16 of the 32 columns per lane
+// half); per micro-block the eight columns are pulled into every lane of their row (a8, cross-half swaps), factorised
+// column by column (pivot sqrt, column division, fmaf updates INSIDE the micro-block: 28 instead of ~200 broadcast /
+// fmaf pairs), stored column-major into Lc (zeros above the diagonal), and then folded into the rest of the tile by
+// FOUR matrix instructions: t -= l l^T over the eight columns in ascending order -- for every element the same
+// fmaf(-l_ic, l_kc, .) chain over ascending c as the scalar sweep (v_mfma_f32_32x32x2_f32 is that chain).  Entries of t
+// in or left of the micro-block are dead afterwards (never read again); entries above the diagonal are scratch.
+template <int M>
+__device__ __forceinline__ void factor32_mb(f32x16& t, int row, int h, int lane, float* Lc) {
+    float a8[8];
 #pragma unroll
-    for (int c = C0; c < C0 + 8; ++c) {
-        a[c] = (row == c) ? d : lic;
-        if (lane < 32) Lc[c * 32 + lane] = (row >= c) ? a[c] : 0.f;
+    for (int i = 0; i < 4; ++i) { a8[i] = lo_half(t[4 * M + i]); a8[4 + i] = hi_half(t[4 * M + i]); }   // columns 8M .. 8M+7 of row `row`
+    float d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[0]), 8 * M)));
+    float lic = a8[0] / d;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * M + c;
+        a8[c] = (row == col) ? d : lic;
+        if (lane < 32) Lc[col * 32 + lane] = (row >= col) ? a8[c] : 0.f;
         const float nl = -lic;
         float dn = 0.f, licn = 0.f;
-        if (c + 1 < 32) {
-            const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), c + 1));
-            a[c + 1] = fmaf(nl, lk1, a[c + 1]);
-            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c + 1]), c + 1)));
-            licn = a[c + 1] / dn;
+        if (c + 1 < 8) {
+            const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c]), col + 1));
+            a8[c + 1] = fmaf(nl, lk1, a8[c + 1]);
+            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c + 1]), col + 1)));
+            licn = a8[c + 1] / dn;
         }
 #pragma unroll
-        for (int k = c + 2; k < 32; ++k) {
-            const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), k));
-            a[k] = fmaf(nl, lkc, a[k]);
+        for (int k = c + 2; k < 8; ++k) {
+            const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c]), 8 * M + k));
+            a8[k] = fmaf(nl, lkc, a8[k]);
         }
         d = dn; lic = licn;
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (M < 3) {
+        // rank-8 update of the tile: A operand and B operand are the same register (t is symmetric in its roles: element
+        // (i, k) -= l_ic l_kc); lane half h supplies the columns of parity h
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = h ? a8[2 * i + 1] : a8[2 * i];
+            t = __builtin_amdgcn_mfma_f32_32x32x2f32(-x, x, t, 0, 0, 0);
+        }
     }
 }
 // diag_solve32 (tile_solve.h: same operations, same order), steps I0 .. I0+7.  The row select is only emitted for the
@@ -307,7 +322,8 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
         const int pidx = (wave - dw) & (kFW - 1);        // 1 .. ncol-1: solves panel tile (j + pidx, j)
         const bool has_panel = pidx >= 1 && pidx < ncol;
         const int pbi = j + pidx;
-        const bool does_z = wave == ((ncol <= kFW - 1) ? ((dw + ncol) & (kFW - 1)) : dw);
+        // z_j: the first wavefront without a panel tile; with eight tiles in the column, the first panel owner does both
+        const bool does_z = wave == ((ncol <= kFW - 1) ? ((dw + ncol) & (kFW - 1)) : ((dw + 1) & (kFW - 1)));
         float* Lc = slots + tri_index(j, j) * 1024;      // in: the diagonal tile (accumulator order); out: its factor, column-major
         f32x16 v;
         float zs = 0.f;
@@ -325,30 +341,39 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
         // ---- P1.  Two roles, separate instruction streams, four workgroup barriers each: stage q of the owner factorises
         // columns 8q .. 8q+7 of the diagonal tile while the others solve their panel tile against columns 8(q-1) ..
         if (wave == dw) {
-            float fa[32], fd = 0.f, flic = 0.f;
+            f32x16 t;
+            {
+                const float4* tt = reinterpret_cast<const float4*>(Lc);
 #pragma unroll
-            for (int k = 0; k < 32; ++k) fa[k] = Lc[d_addr(l31, k)];      // row l31 of the tile
+                for (int g = 0; g < 4; ++g) {
+                    const float4 q = tt[g * 64 + lane];
+                    t[4 * g] = q.x; t[4 * g + 1] = q.y; t[4 * g + 2] = q.z; t[4 * g + 3] = q.w;
+                }
+            }
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();                                // (the factor overwrites the slot)
-            factor32_seg<0>(fa, l31, lane, Lc, fd, flic);
+            factor32_mb<0>(t, l31, h, lane, Lc);
             wg_sync();
-            factor32_seg<8>(fa, l31, lane, Lc, fd, flic);
+            factor32_mb<1>(t, l31, h, lane, Lc);
             wg_sync();
-            factor32_seg<16>(fa, l31, lane, Lc, fd, flic);
+            factor32_mb<2>(t, l31, h, lane, Lc);
             wg_sync();
-            factor32_seg<24>(fa, l31, lane, Lc, fd, flic);
+            factor32_mb<3>(t, l31, h, lane, Lc);
             wg_sync();
             if (lane < 32) Ldiag[32 * j + lane] = Lc[lane * 32 + lane];
-            if (does_z) { zs = yv[32 * j + l31]; z_seg(0); z_seg(8); z_seg(16); z_seg(24); }
         } else {
-            // column j-1 to the tiles right of column j (dealt to the seven wavefronts): matrix work under the factorisation
-            if (j > 0) {
-                const int widx = pidx - 1;
-                int m = 0;
-                for (int c = j + 1; c < nb; ++c)
-                    for (int bi = c; bi < nb; ++bi, ++m)
-                        if (m % (kFW - 1) == widx) apply_column(bi, c, j - 1);
-            }
+            // column j-1 to the tiles right of column j: dealt to the seven wavefronts, one product per stage, so that the
+            // matrix work runs under the serial factorisation and never delays a stage barrier by more than one product
+            const int widx = pidx - 1;
+            const int nrest = (j > 0) ? (nb - j - 1) * (nb - j) / 2 : 0;
+            auto rest_item = [&](int stage) __attribute__((always_inline)) {
+                const int m = widx + (kFW - 1) * stage;
+                if (m < nrest) {
+                    int c = j + 1, rem = m;
+                    while (rem >= nb - c) { rem -= nb - c; ++c; }
+                    apply_column(c + rem, c, j - 1);
+                }
+            };
             if (has_panel) {
                 const float4* tt = reinterpret_cast<const float4*>(slots + tri_index(pbi, j) * 1024);
 #pragma unroll
@@ -358,14 +383,22 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
                 }
             }
             if (does_z) zs = yv[32 * j + l31];
+            rest_item(0);
             wg_sync();
-            if (has_panel) diag_solve8<0>(v, Lc, h); else if (does_z) z_seg(0);
+            if (has_panel) diag_solve8<0>(v, Lc, h);
+            if (does_z) z_seg(0);
+            rest_item(1);
             wg_sync();
-            if (has_panel) diag_solve8<8>(v, Lc, h); else if (does_z) z_seg(8);
+            if (has_panel) diag_solve8<8>(v, Lc, h);
+            if (does_z) z_seg(8);
+            rest_item(2);
             wg_sync();
-            if (has_panel) diag_solve8<16>(v, Lc, h); else if (does_z) z_seg(16);
+            if (has_panel) diag_solve8<16>(v, Lc, h);
+            if (does_z) z_seg(16);
+            rest_item(3);
             wg_sync();
-            if (has_panel) diag_solve8<24>(v, Lc, h); else if (does_z) z_seg(24);
+            if (has_panel) diag_solve8<24>(v, Lc, h);
+            if (does_z) z_seg(24);
         }
         if (has_panel) {
             float* tile = slots + tri_index(pbi, j) * 1024;

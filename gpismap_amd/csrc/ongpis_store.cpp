@@ -223,7 +223,9 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     // workgroup per cluster is faster; few workgroups per cluster (so that MANY clusters fit the launch) beat many workgroups
     // for few clusters -- a cooperative cluster is bound by its serial path, and every large cluster left to the
     // one-workgroup kernel costs more than a small G costs the largest ones.
-    int kCoopMinNb = 32, kCoopMaxWG = 240;
+    static int coop_capacity = 0;    // resident workgroups of the cooperative kernel on this device (queried once)
+    if (!coop_capacity) coop_capacity = std::max(2, ongpis_coop_capacity());
+    int kCoopMinNb = 32, kCoopMaxWG = coop_capacity;
     int kCoopGDiv = 900, kCoopGMax = 6;
 #ifdef GPIS_K3_TUNE
     if (const char* e = getenv("K3_MINNB")) kCoopMinNb = atoi(e);
@@ -323,7 +325,10 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         GPIS_HIP(hipEventRecord(ev0_, s));
     }
     if (!d_err_) GPIS_HIP(hipMalloc(&d_err_, sizeof(int) * 4));
-    GPIS_HIP(hipMemsetAsync(d_err_, 0, sizeof(int) * 4, s));
+    {
+        const int ctl[4] = {0, debug_inject, wait_limit_ticks, 0};
+        GPIS_HIP(hipMemcpyAsync(d_err_, ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
+    }
     if (nsep > 0) {
         ongpis_launch_gather(d_models_, d_jobs_, nsep, d_ids_, pts_.d, pts_.cap, s);
         ongpis_launch_buildK(d_models_, d_jobs_, nsep, s);
@@ -354,10 +359,10 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         const int nbeg = gbeg[grp], ncnt = gbeg[grp + 1] - gbeg[grp];
         if (ncnt <= 0) continue;
         if (grp > 0) GPIS_HIP(hipStreamWaitEvent(gs[grp], evf_, 0));
-        if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), gs[0]);
+        if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
-        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], gs[grp]);
+        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], d_err_, gs[grp]);
         if (grp == 1) { GPIS_HIP(hipEventRecord(evj3_, s3_)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
         if (grp == 2) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     }
@@ -368,7 +373,17 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     GPIS_HIP(hipStreamSynchronize(s));
     if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
     if (h_err[0]) {
-        fprintf(stderr, "[gpismap_amd] training kernels reported error word 0x%x: the batch is not usable\n", h_err[0]);
+        // bit 0: a job the fused kernel cannot hold; bit 1: a wait of the cooperative factorisation expired; bit 2: a row
+        // wait of the inverse expired.  The factors of this batch may be incomplete: every model of the batch is marked
+        // untrained (test() treats the cells as having no GP) and the caller gets GPIS_ERR_STATE.
+        fprintf(stderr, "[gpismap_amd] training kernels reported error word 0x%x: the %d models of this batch are dropped\n", h_err[0], nj);
+        for (int j = 0; j < nj; ++j) {
+            ClusterModel& m = models_[tab[4 * j]];
+            if (m.base) pool_free(pool_, m.base);
+            std::memset(&m, 0, sizeof(ClusterModel));
+        }
+        dirty_ = true;
+        (void)sync_models(s);
         return GPIS_ERR_STATE;
     }
     return deferred_rc;

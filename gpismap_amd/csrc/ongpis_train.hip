@@ -13,6 +13,7 @@
 //  chol   : LEFT-looking 32-blocked Cholesky; the tiles of the current block column live in MFMA
 //           accumulators (v_mfma_f32_32x32x2_f32, a k-ordered fmaf chain => same bits as the
 //           unblocked chain order), then blocked backward substitution for alpha (details at K3 below).
+#include <algorithm>
 #include "ongpis.h"
 #include "tile_solve.h"
 
@@ -487,10 +488,15 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
 // at most one workgroup per CU (<= 240 in total), so every workgroup of a cluster becomes resident and the waits end.
 // The blocked back-substitution for alpha runs on workgroup 0 of the cluster after all rows are done.
 // ---------------------------------------------------------------------------
+// Every wait is bounded by the device's constant 100 MHz clock (ctl[2] ticks, default 2 s -- a cooperative cluster takes
+// milliseconds): on expiry the waiting workgroup ORs bit 1 into the error word ctl[0], raises the cluster's abort flag so
+// that its partners stop too, and leaves; the host reads the word after the batch and reports GPIS_ERR_STATE (the batch
+// is not usable).  ctl[1] bit 0 is test-only fault injection: the owner of block row 1 "forgets" to publish it.
 __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterModel* __restrict__ models,
                                                                 const int* __restrict__ d_jobs, const int* __restrict__ cwork,
-                                                                int* __restrict__ sync) {
+                                                                int* __restrict__ sync, int* __restrict__ ctl) {
     constexpr int NW = 8;
+    __shared__ int abort_s;
     __shared__ __attribute__((aligned(16))) float D[32 * 33];
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];
     __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
@@ -506,8 +512,11 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     const int ntl = nbr * (nbr + 1) / 2;
     const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
-    int* rowready = sync + 2 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially)
+    int* rowready = sync + 2 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially);
+                                         // negative: a workgroup of this cluster gave up (abort)
     int* alldone = sync + 2 * job + 1;   // workgroups that have finished their rows
+    const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
+    const bool inject = (ctl[1] & 1) != 0;
     auto load_tile = [&](float (&o)[16], int b, int c) {
         const int sbase = tri_index(b, c) * 4096;
 #pragma unroll
@@ -517,13 +526,27 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
         }
     };
-    auto wait_flag = [&](int* f, int v) {     // one lane polls a device-scope flag, then the workgroup acquires
+    // one lane polls a device-scope flag, then the workgroup acquires; false: the wait expired or a partner aborted
+    auto wait_flag = [&](int* f, int v) -> bool {
         if (tid == 0) {
-            long spins = 0;
-            while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < v && ++spins < (1L << 28)) __builtin_amdgcn_s_sleep(8);
+            const long long t0 = wall_clock64();
+            int ok = 1;
+            for (;;) {
+                if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) break;
+                if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) { ok = 0; break; }
+                if (wall_clock64() - t0 > wait_ticks) {
+                    ok = 0;
+                    atomicOr(ctl, 2);
+                    __hip_atomic_store(rowready, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            abort_s = !ok;
         }
         __syncthreads();
+        return abort_s == 0;
     };
 
     for (int j = 0; j < nb; ++j) {
@@ -589,16 +612,18 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
             }
             __syncthreads();
-            if (tid == 0) {
+            if (tid == 0 && !(inject && j == 1)) {
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(rowready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (an abort mark of a partner must survive: only move the counter forward from a non-negative value)
+                if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
+                    __hip_atomic_store(rowready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
         // ---- everybody: acquire row j, then the owned rows below it
         const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
         if (first >= nbr) continue;                                   // nothing left for this workgroup in later columns either
-        wait_flag(rowready, j + 1);
+        if (!wait_flag(rowready, j + 1)) return;      // expired / aborted: error word set, the cluster is abandoned
         if (j % G != g) {     // non-owners rebuild the padded diagonal factor from the published block
             for (int idx = tid; idx < 1024; idx += 512) {
                 const int c = idx >> 5, r = idx & 31;
@@ -671,7 +696,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
         __hip_atomic_fetch_add(alldone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (g != 0) return;
-    wait_flag(alldone, G);
+    if (!wait_flag(alldone, G)) return;
     chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
 }
 
@@ -700,7 +725,8 @@ constexpr int kMidWaves = 8;    // the one-wavefront columns of the larger clust
 // kShortWaves) adjacent columns of one cluster per workgroup; the work entry names the first of them.
 template <int NWI, bool REGZ>
 __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)), REGZ ? 3 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
-                                                               const int* __restrict__ d_jobs, const int* __restrict__ work) {
+                                                               const int* __restrict__ d_jobs, const int* __restrict__ work,
+                                                               int* __restrict__ ctl) {
     __shared__ __attribute__((aligned(16))) float Tall[REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)][32 * 36];
     __shared__ int rowdone_s;
     typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;
@@ -764,7 +790,7 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
         if (NWI > 1) {
             __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0) *rowdone = b;
+            if (lane == 0 && *rowdone >= 0) *rowdone = b;
         }
     };
     auto times_inverse = [&](const f32x16& sacc, int b) {   // inv(L_bb) * S, S = accumulator tile as the B operand
@@ -867,9 +893,22 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
         while (p < b) {
             int pe = b - 1;                 // last row usable now
             if (NWI > 1) {
+                // rows of the column appear in order (LDS counter).  The wait is bounded by the 100 MHz clock; on expiry --
+                // a protocol error, the rows are published by this very workgroup -- bit 2 of the error word is set and the
+                // wavefront abandons its rows (never re-accumulating: p only moves forward); a negative counter tells the
+                // other wavefronts of the column to stop as well.
                 int avail = *rowdone;
-                long spins = 0;   // bounded like the cooperative kernel's waits: a protocol error must not hang the device
-                while (avail < p && ++spins < (1L << 27)) { __builtin_amdgcn_s_sleep(1); avail = *rowdone; }
+                const long long t0 = wall_clock64();
+                while (avail >= 0 && avail < p) {
+                    if (wall_clock64() - t0 > (ctl[2] > 0 ? (long long)ctl[2] : 200000000LL)) {
+                        if (lane == 0) { atomicOr(ctl, 4); *rowdone = -1; }
+                        avail = -1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    avail = *rowdone;
+                }
+                if (avail < 0) return;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 pe = min(avail, b - 1);
             }
@@ -931,16 +970,26 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
-void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, hipStream_t s) {
-    if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync);
+void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
+    if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync, d_ctl);
+}
+// workgroups of the cooperative kernel that can be resident at once on the current device (its waits need every workgroup
+// of a cluster running): CUs x occupancy, less a sixteenth as a margin for the kernels of the other size groups
+int ongpis_coop_capacity() {
+    int dev = 0, ncu = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ongpis_chol_coop_kernel, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    // one workgroup per CU is what the schedule is tuned for (the largest clusters want a CU's matrix pipes to themselves)
+    return std::max(2, ncu - ncu / 16);
 }
 
-void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, hipStream_t s) {
+void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, int* d_ctl, hipStream_t s) {
     // the work list starts with the long columns (8 cooperating wavefronts each), then the columns that take one wavefront
     // and exchange their transposed tiles through Zt, then the columns of at most kShortRows rows (tiles kept in registers)
-    if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8, false>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work);
-    if (nmid > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, false>), dim3(nmid), dim3(64 * kMidWaves), 0, s, d_models, d_jobs, d_work + 2 * nlong);
-    if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, true>), dim3(nshort), dim3(64 * kShortWaves), 0, s, d_models, d_jobs, d_work + 2 * (nlong + nmid));
+    if (nlong > 0) hipLaunchKernelGGL((ongpis_inv_kernel<8, false>), dim3(nlong), dim3(512), 0, s, d_models, d_jobs, d_work, d_ctl);
+    if (nmid > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, false>), dim3(nmid), dim3(64 * kMidWaves), 0, s, d_models, d_jobs, d_work + 2 * nlong, d_ctl);
+    if (nshort > 0) hipLaunchKernelGGL((ongpis_inv_kernel<1, true>), dim3(nshort), dim3(64 * kShortWaves), 0, s, d_models, d_jobs, d_work + 2 * (nlong + nmid), d_ctl);
 }
 int ongpis_inverse_short_rows() { return kShortRows; }
 int ongpis_inverse_short_waves() { return kShortWaves; }

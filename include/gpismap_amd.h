@@ -144,6 +144,11 @@ int   gpis_ongpis_set_exp_table(void* s, int on);
 int   gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out);
 int   gpis_ongpis_set_keep_factor(void* s, int on);
 int   gpis_ongpis_set_fused(void* s, int on);
+/* In-kernel waits (the cooperative factorisation of the largest clusters, the pipelined inverse) are bounded: when one
+ * expires the batch's models are dropped and training returns GPIS_ERR_STATE.  wait_limit_ms = 0 keeps the default
+ * (2 s); inject != 0 is a TEST hook that makes one workgroup of every cooperative cluster withhold a hand-over, so that
+ * the error path can be exercised. */
+int   gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 
 #ifdef __cplusplus

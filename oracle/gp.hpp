@@ -70,7 +70,8 @@ struct GPou {
             }
         chol_lower_m(L.data(), n, n);
         alpha.assign(f, f + n);
-        fwd_subst_m(L.data(), n, n, alpha.data(), 1, n);
+        if (arith_mode() == ARITH_EIGEN33) eig::fwd_vec(L.data(), n, n, alpha.data());   // vector right-hand side (ObsGP.cpp:43)
+        else fwd_subst_m(L.data(), n, n, alpha.data(), 1, n);
         bwd_subst_m(L.data(), n, n, alpha.data());
         trained = true;
     }
@@ -86,6 +87,12 @@ struct GPou {
         for (int i = 0; i < n; ++i) {
             ks[i] = ou_k(dist_n(&x[(size_t)dim * i], xt, dim), a);
             p[i] = ks[i] * alpha[i];
+        }
+        if (arith_mode() == ARITH_EIGEN33) {   // ObsGP.cpp:54-59 in Eigen 3.3's orders (linalg.hpp)
+            f = eig::dot(ks, alpha.data(), n);
+            eig::fwd_mat(L.data(), n, n, ks, 1, 64);
+            var = (1 + noise) - eig::sum_sq_seq(ks, n);
+            return;
         }
         if (arith_mode() != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
             const bool d64 = arith_mode() == ARITH_FP64ACC;
@@ -427,7 +434,8 @@ struct OnGPIS {
         mode = arith_mode();
         chol_lower_m(L.data(), K, K);
         alpha = y;
-        fwd_subst_m(L.data(), K, K, alpha.data(), 1, K);
+        if (mode == ARITH_EIGEN33) eig::fwd_vec(L.data(), K, K, alpha.data());   // vector right-hand side (OnGPIS.cpp:142)
+        else fwd_subst_m(L.data(), K, K, alpha.data(), 1, K);
         bwd_subst_m(L.data(), K, K, alpha.data());
         if (arith_mode() == ARITH_TILED) {
             // Explicit inverse of the factor (tiled mode).  A prediction needs V = L^-1 k*; with X = L^-1 formed once
@@ -491,6 +499,19 @@ struct OnGPIS {
         const int nc = 1 + dim;
         std::vector<float> ks((size_t)K * nc);
         matern32_cross1(dim, N, x.data(), gidx.data(), ng, scale, xq, ks.data(), K);
+        if (mode == ARITH_EIGEN33) {   // OnGPIS.cpp:187-213 in Eigen 3.3's orders (linalg.hpp)
+            std::vector<float> zero(nc, 0.f);
+            // K^T alpha: row-major GEMV kernel over the nc columns of k* (contiguous, leading dimension K)
+            eig::gemv_row(nc, K, ks.data(), K, alpha.data(), zero.data(), 1.f);
+            for (int c = 0; c < nc; ++c) mean[c] = zero[c];
+            eig::fwd_mat(L.data(), K, K, ks.data(), nc, K);
+            for (int c = 0; c < nc; ++c) {
+                const float s = eig::sum_sq_seq(&ks[(size_t)c * K], K);
+                if (dim == 3) var[c] = (c == 0) ? (float)(1.001 - (double)s) : (float)((double)three_over_scale + 0.001 - (double)s);
+                else var[c] = (c == 0) ? (float)(1.01 - (double)s) : (float)((double)three_over_scale + 0.1 - (double)s);
+            }
+            return;
+        }
         if (mode != ARITH_TILED) {   // order variants (linalg.hpp): sequential sums, plain substitution
             const bool d64 = mode == ARITH_FP64ACC;
             for (int c = 0; c < nc; ++c) {

@@ -118,8 +118,8 @@ int orc2_obsgp_sizes(void* h, int* out, int cap) {
 }
 
 // ---- component level -------------------------------------------------------
-// arithmetic variant of every subsequent training / prediction (linalg.hpp): 0 tiled (default), 1 natural, 2 fp64acc
-void orc_set_arith_mode(int m) { arith_mode() = (m == 1 || m == 2) ? m : 0; }
+// arithmetic variant of every subsequent training / prediction (linalg.hpp): 0 tiled (default), 1 natural, 2 fp64acc, 3 eigen33
+void orc_set_arith_mode(int m) { arith_mode() = (m >= 1 && m <= 3) ? m : 0; }
 int orc_get_arith_mode() { return arith_mode(); }
 void orc_chol_lower(float* A, int n, int ld) { chol_lower(A, n, ld); }
 void orc_fwd_subst(const float* L, int n, int ld, float* B, int nrhs, int ldb) { fwd_subst(L, n, ld, B, nrhs, ldb); }

@@ -75,13 +75,14 @@ def lib():
     return _LIB
 
 
-ARITH_MODES = {"tiled": 0, "natural": 1, "fp64acc": 2}
+ARITH_MODES = {"tiled": 0, "natural": 1, "fp64acc": 2, "eigen33": 3}
 
 
 def set_arith_mode(mode):
     """Arithmetic variant of every subsequent oracle training / prediction (oracle/linalg.hpp): "tiled" (default;
     the orders the HIP kernels reproduce bit for bit), "natural" (plain left-to-right fp32, no fma, plain
-    substitution) or "fp64acc" (natural order with double accumulators).  Process-global; reset to "tiled" after use."""
+    substitution), "fp64acc" (natural order with double accumulators) or "eigen33" (the orders of Eigen 3.3's published
+    blocked LLT / triangular solves / reductions, restated from memory: a proxy, parity stays unpinned).  Process-global; reset to "tiled" after use."""
     lib().orc_set_arith_mode(ARITH_MODES[mode] if isinstance(mode, str) else int(mode))
 
 

@@ -227,3 +227,26 @@ def test_fused_training_equals_separate_kernels(dim, scale, sizes):
                 st.model(models[0])
     assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
     assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
+
+
+def test_cooperative_wait_expiry_is_reported():
+    """The largest clusters are factorised by several workgroups handing block rows over through device-scope flags.  A
+    hand-over that never arrives (injected here) must not hang the device or yield a garbage factor silently: the bounded
+    wait expires, the batch is dropped and training reports GPIS_ERR_STATE; the store stays usable afterwards."""
+    import gpismap_amd
+    rng = np.random.default_rng(99)
+    n = 300
+    pos, grad, val, sx, sg = make_cluster(rng, 3, n, 0.04, frac_nograd=0.0)      # K = 1200: 38 block rows -> cooperative
+    P = soa9(3, pos, grad, val, sx, sg)
+    off = np.array([0, n], dtype=np.int32); ids = np.arange(n, dtype=np.int32)
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    st.set_debug(inject=1, wait_limit_ms=20)
+    with pytest.raises(gpismap_amd.GpisError) as e:
+        st.train(P, off, ids)
+    assert "-3" in str(e.value)                                                   # GPIS_ERR_STATE
+    st.set_debug(inject=0, wait_limit_ms=0)
+    models = st.train(P, off, ids)
+    xq = (pos[:16] + rng.normal(0, 0.01, (16, 3))).astype(np.float32)
+    out = st.eval(xq, np.arange(16, dtype=np.int32), np.full(16, models[0], dtype=np.int32))
+    ref = oracle_lib.ongpis_predict(3, 0.04, pos, grad, val, sx, sg, xq)
+    assert np.array_equal(np.concatenate([out[:, :4], out[:, 4:8]], axis=1).view(np.uint32), ref.view(np.uint32))
