@@ -85,6 +85,9 @@ def lib():
     L.gpis_ongpis_create.restype = vp
     L.gpis_ongpis_create.argtypes = [C.c_int, C.c_float]
     L.gpis_ongpis_destroy.argtypes = [vp]
+    L.gpis3_create_multi.restype = vp
+    L.gpis3_create_multi.argtypes = [C.c_void_p, ip, C.c_int]
+    L.gpis3_num_devices.argtypes = [vp]
     L.gpis_ongpis_train.argtypes = [vp, fp, C.c_int, ip, ip, C.c_int, ip]
     L.gpis_ongpis_model_dims.argtypes = [vp, C.c_int, ip]
     L.gpis_ongpis_get_model.argtypes = [vp, C.c_int, fp, fp, ip]
@@ -130,13 +133,23 @@ class GPisMap3:
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
                  "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK")
 
-    def __init__(self, cam6=None):
+    def __init__(self, cam6=None, devices=None):
+        """devices: list of HIP device ids for ONE map over several devices (gpis3_create_multi; a device may repeat:
+        logical shards on one GPU); None = the current device (or GPIS_DEVICES from the environment)."""
         self.L = lib()
         if self.L.gpis_device_count() < 1:
             raise GpisError("no HIP device: gpismap_amd has no CPU fallback")
-        self.h = C.c_void_p(self.L.gpis3_create(C.byref(_cam(cam6)) if cam6 is not None else None))
+        cam = C.byref(_cam(cam6)) if cam6 is not None else None
+        if devices is None:
+            self.h = C.c_void_p(self.L.gpis3_create(cam))
+        else:
+            d = np.ascontiguousarray(devices, dtype=np.int32)
+            self.h = C.c_void_p(self.L.gpis3_create_multi(cam, _p(d, C.c_int), d.size))
         if not self.h:
             raise GpisError("gpis3_create failed")
+
+    def num_devices(self):
+        return int(self.L.gpis3_num_devices(self.h))
 
     def close(self):
         if getattr(self, "h", None):

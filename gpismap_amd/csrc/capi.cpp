@@ -20,6 +20,8 @@ int gpis2_impl_fail(GPisMap* m);
 int gpis3_impl_update_fail(GPisMap3* m);
 int gpis2_impl_update_fail(GPisMap* m);
 int gpis3_impl_device(GPisMap3* m);
+int gpis3_impl_num_devices(GPisMap3* m);
+GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, const int* devices, int n);
 int gpis3_impl_set_shard(GPisMap3* m, int rank, int world);
 int gpis3_impl_shard_info(GPisMap3* m, int* out, int n);
 long long gpis3_impl_shard_packed_bytes(GPisMap3* m);
@@ -55,6 +57,16 @@ void* gpis3_create(const gpis_cam* cam) {
         return new GPisMap3(p);
     } catch (...) { return nullptr; }
 }
+void* gpis3_create_multi(const gpis_cam* cam, const int* devices, int n) {
+    if (!devices || n < 1) return nullptr;
+    try {
+        GPisMap3Param p;
+        camParam c;
+        if (cam) c = camParam(cam->fx, cam->fy, cam->cx, cam->cy, (float)cam->width, (float)cam->height);
+        return gpis3_impl_create_on(p, c, devices, n);
+    } catch (...) { return nullptr; }
+}
+int gpis3_num_devices(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_num_devices((GPisMap3*)m); }
 void gpis3_destroy(void* m) { delete (GPisMap3*)m; }
 int gpis3_reset(void* m) { if (!m) return GPIS_ERR_ARG; ((GPisMap3*)m)->reset(); return GPIS_OK; }
 int gpis3_set_camera(void* m, const gpis_cam* cam) {
@@ -92,11 +104,11 @@ int gpis3_set_shard(void* m, int rank, int world) {
 int gpis3_shard_info(void* m, int* out, int n) { if (!m || !out) return GPIS_ERR_ARG; return gpis3_impl_shard_info((GPisMap3*)m, out, n); }
 long long gpis3_shard_packed_bytes(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_packed_bytes((GPisMap3*)m); }
 int gpis3_shard_pack(void* m, void* d_buf, long long stride, void* stream) {
-    if (!m || stride < 256) return GPIS_ERR_ARG;
+    if (!m || stride < 256 || stride % 256 != 0) return GPIS_ERR_ARG;
     return gpis3_impl_shard_pack((GPisMap3*)m, d_buf, stride, stream);
 }
 int gpis3_shard_unpack(void* m, int owner, const void* d_buf, int n, long long stride, void* stream) {
-    if (!m || stride < 256 || n < 0) return GPIS_ERR_ARG;
+    if (!m || stride < 256 || stride % 256 != 0 || n < 0) return GPIS_ERR_ARG;
     return gpis3_impl_shard_unpack((GPisMap3*)m, owner, d_buf, n, stride, stream);
 }
 int gpis3_shard_finish(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_finish((GPisMap3*)m); }
@@ -156,30 +168,32 @@ int gpis2_get_nodes(void* m, float* out, int cap) {
 int gpis2_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis2_impl_stats((GPisMap*)m, out, n); return GPIS_OK; }
 
 // ---- ObsGP --------------------------------------------------------------------
-struct ObsHandle { ObsGPDevice g; hipStream_t s = nullptr; };
+struct ObsHandle { int device = -1; ObsGPDevice g; hipStream_t s = nullptr; };
 void* gpis_obsgp_create(void) {
     if (gpis_device_count() < 1) { fprintf(stderr, "[gpismap_amd] no HIP device\n"); return nullptr; }
     ObsHandle* h = new (std::nothrow) ObsHandle();
+    if (h) (void)hipGetDevice(&h->device);
     if (h && hipStreamCreate(&h->s) != hipSuccess) { delete h; return nullptr; }
     return h;
 }
-void gpis_obsgp_destroy(void* g) { if (!g) return; ObsHandle* h = (ObsHandle*)g; if (h->s) (void)hipStreamDestroy(h->s); delete h; }
+void gpis_obsgp_destroy(void* g) { if (!g) return; ObsHandle* h = (ObsHandle*)g; DeviceScope dev_scope_(h->device); if (h->s) (void)hipStreamDestroy(h->s); delete h; }
 int gpis_obsgp_train2d(void* g, const float* vu, const float* f, int ni, int nj) {
-    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.train2d(vu, f, ni, nj, h->s);
+    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; DeviceScope dev_scope_(h->device); return h->g.train2d(vu, f, ni, nj, h->s);
 }
 int gpis_obsgp_train1d(void* g, const float* th, const float* f, int n) {
-    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.train1d(th, f, n, h->s);
+    if (!g) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; DeviceScope dev_scope_(h->device); return h->g.train1d(th, f, n, h->s);
 }
 int gpis_obsgp_query(void* g, const float* q, int nq, float* val, float* var) {
-    if (!g || !q || !val || !var) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.query(q, nq, val, var, h->s);
+    if (!g || !q || !val || !var) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; DeviceScope dev_scope_(h->device); return h->g.query(q, nq, val, var, h->s);
 }
 int gpis_obsgp_num_groups(void* g) { if (!g) return GPIS_ERR_ARG; return ((ObsHandle*)g)->g.ngroups(); }
 int gpis_obsgp_get_group(void* g, int group, int* n, float* x, float* alpha, float* L) {
-    if (!g || !n) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; return h->g.get_group(group, n, x, alpha, L, h->s);
+    if (!g || !n) return GPIS_ERR_ARG; ObsHandle* h = (ObsHandle*)g; DeviceScope dev_scope_(h->device); return h->g.get_group(group, n, x, alpha, L, h->s);
 }
 
 // ---- OnGPIS -------------------------------------------------------------------
 struct OnHandle {
+    int device = -1;     // the device current at creation: every entry makes it current for its duration
     OnGPISStore st; hipStream_t s = nullptr;
     float* d_xq = nullptr; float* d_out = nullptr; size_t cap_xq = 0, cap_out = 0;
     OnHandle(int dim, float scale) : st(dim, scale) {}
@@ -188,12 +202,14 @@ void* gpis_ongpis_create(int dim, float scale) {
     if (dim != 2 && dim != 3) return nullptr;
     if (gpis_device_count() < 1) { fprintf(stderr, "[gpismap_amd] no HIP device\n"); return nullptr; }
     OnHandle* h = new (std::nothrow) OnHandle(dim, scale);
+    if (h) (void)hipGetDevice(&h->device);
     if (h && hipStreamCreate(&h->s) != hipSuccess) { delete h; return nullptr; }
     if (h) h->st.profile = true;
     return h;
 }
 void gpis_ongpis_destroy(void* s) {
     if (!s) return; OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     (void)hipFree(h->d_xq); (void)hipFree(h->d_out);
     if (h->s) (void)hipStreamDestroy(h->s);
     delete h;
@@ -201,6 +217,7 @@ void gpis_ongpis_destroy(void* s) {
 int gpis_ongpis_train(void* s, const float* soa9, int npts, const int* off, const int* ids, int ncl, int* model_out) {
     if (!s || !soa9 || !off || !ids || ncl < 0) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     int dim = h->st.dim();
     int rc = h->st.upload_points(soa9, npts, h->s);
     if (rc) return rc;
@@ -230,6 +247,7 @@ int gpis_ongpis_model_dims(void* s, int model, int* d4) {
 int gpis_ongpis_get_model(void* s, int model, float* L, float* alpha, int* gidx) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     const ClusterModel* m = h->st.model(model);
     if (!m || !m->base) return GPIS_ERR_ARG;
     if (!m->L) return GPIS_ERR_STATE;   // imported (predict-only) model: no factor on this rank
@@ -242,6 +260,7 @@ int gpis_ongpis_get_model(void* s, int model, float* L, float* alpha, int* gidx)
 int gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs, float* out8) {
     if (!s || !xq || !job_q || !job_model || !out8 || nq < 1 || njobs < 1) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     int dim = h->st.dim();
     std::vector<float> x4((size_t)4 * nq, 0.f);
     for (int i = 0; i < nq; ++i) for (int d = 0; d < dim; ++d) x4[(size_t)4 * i + d] = xq[(size_t)dim * i + d];
@@ -261,13 +280,15 @@ long long gpis_ongpis_packed_bytes(void* s, const int* models, int n) {
     return (long long)((OnHandle*)s)->st.packed_bytes(models, n);
 }
 int gpis_ongpis_pack(void* s, const int* models, int n, void* d_buf, long long stride, void* stream) {
-    if (!s || !models || !d_buf || n < 0 || stride < 256) return GPIS_ERR_ARG;
+    if (!s || !models || !d_buf || n < 0 || stride < 256 || stride % 256 != 0) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     return h->st.pack_models(models, n, d_buf, (size_t)stride, stream ? (hipStream_t)stream : h->s);
 }
 int gpis_ongpis_unpack(void* s, const void* d_buf, int n, long long stride, int* models_inout, void* stream) {
-    if (!s || !d_buf || !models_inout || n < 0 || stride < 256) return GPIS_ERR_ARG;
+    if (!s || !d_buf || !models_inout || n < 0 || stride < 256 || stride % 256 != 0) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     return h->st.unpack_models(d_buf, n, (size_t)stride, models_inout, stream ? (hipStream_t)stream : h->s);
 }
 int gpis_ongpis_set_exp_table(void* s, int on) {
@@ -278,6 +299,7 @@ int gpis_ongpis_set_exp_table(void* s, int on) {
 int gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     return h->st.kernel_matrix(x, gidx, sigx, sigg, n, K_out, h->s);
 }
 int gpis_ongpis_set_keep_factor(void* s, int on) {
@@ -293,6 +315,7 @@ int gpis_ongpis_set_fused(void* s, int on) {
 int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {
     if (!s || wait_limit_ms < 0 || wait_limit_ms > 20000) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     h->st.debug_inject = inject;
     h->st.wait_limit_ticks = wait_limit_ms * 100000;     // 100 MHz device clock
     return GPIS_OK;
@@ -300,6 +323,7 @@ int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {
 int gpis_ongpis_last_ms(void* s, float* t, float* e) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
     if (t) *t = h->st.last_train_ms;
     if (e) *e = h->st.last_eval_ms;
     return GPIS_OK;

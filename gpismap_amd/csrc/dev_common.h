@@ -71,6 +71,10 @@ struct DeviceScope {
     ~DeviceScope() { if (dev >= 0 && prev >= 0 && prev != dev) (void)hipSetDevice(prev); }
 };
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (device, kernel): the attribute is per device, and one process may
+// drive maps on several GPUs.  Thread safe.  Returns GPIS_OK or GPIS_ERR_HIP.
+int ensure_dynamic_lds(const void* kernel, int bytes);
+
 // Simple caching device allocator (size-class free lists).  Not thread safe:
 // one map object = one caller thread, as in the reference.
 struct DevPool;

@@ -9,6 +9,8 @@
 // re-evaluates them because it fetches each cluster's node list lazily, :308-311)
 // are handled by an on-demand batch when that cluster is reached.
 #include <algorithm>
+#include <thread>
+#include <cstdlib>
 #include <array>
 #include <cmath>
 #include <chrono>
@@ -21,10 +23,18 @@
 #include "obsgp.h"
 #include "ongpis.h"
 
+// (defined at the end of this file; used by the several-devices paths above them)
+GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, const int* devices, int n);
+int gpis3_impl_shard_info(GPisMap3* g, int* out, int n);
+long long gpis3_impl_shard_packed_bytes(GPisMap3* g);
+int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, long long stride, void* stream);
+int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, int n, long long stride, void* stream);
+int gpis3_impl_shard_finish(GPisMap3* g);
+
 using namespace gpis;
 
-// Fine-grained host timing of update() for tools/update_profile.py: only in builds with -DGPIS_UPDATE_TRACE.
-#ifdef GPIS_UPDATE_TRACE
+// Fine-grained host timing of update() for tools/update_profile.py: only in builds with -DGPIS_INSTRUMENT.
+#ifdef GPIS_INSTRUMENT
 struct UpdLap {
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void operator()(const char* what) {
@@ -115,6 +125,18 @@ struct GPisMap3::Impl {
     bool table_pending = false;   // update() trained the local share only: the cluster table waits for the exchange
     void build_cluster_table();
 
+    // ---- several devices behind ONE map object (GPIS_DEVICES=0,1,... or gpis3_create_multi): this instance is rank 0,
+    // `peers` are ranks 1..n-1, each a complete map on its own device.  update(): every rank runs the same deterministic
+    // host logic on its own host thread and trains its K^3-balanced share of the frame's clusters; the packed models
+    // travel device to device (hipMemcpyPeer), are unpacked as predict-only models and every rank builds its table.
+    // test(): the queries are dealt to the ranks in blocks of kQueryBlock rows round-robin and answered concurrently;
+    // per-query arithmetic does not depend on the cut, so the result is bit-identical to a single-device map.
+    // (Reference: the fan-out inside the call over host threads, GPisMap3.cpp:759-784 and :904-949.)
+    std::vector<GPisMap3*> peers;
+    void* d_send = nullptr; size_t cap_send = 0;
+    void* d_recv = nullptr; size_t cap_recv = 0;
+    static constexpr int kQueryBlock = 65536;
+
     Impl(const GPisMap3Param& par, const camParam& c)
         : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
           mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
@@ -123,7 +145,7 @@ struct GPisMap3::Impl {
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
     ~Impl() {
-        (void)hipFree(d_x); (void)hipFree(d_res);
+        (void)hipFree(d_x); (void)hipFree(d_res); (void)hipFree(d_send); (void)hipFree(d_recv);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
@@ -686,29 +708,154 @@ static void nothrow_report(const char* where, const char* what) {
     fprintf(stderr, "[gpismap_amd] %s: exception contained (%s)\n", where, what);
 }
 
-GPisMap3::GPisMap3() : p_(new Impl(GPisMap3Param(), camParam())) {}
-GPisMap3::GPisMap3(GPisMap3Param par) : p_(new Impl(par, camParam())) {}
-GPisMap3::GPisMap3(GPisMap3Param par, camParam c) : p_(new Impl(par, c)) {}
+// Device list of a map object: GPIS_DEVICES=0,1,2,... (a device may repeat: logical shards on one GPU); empty = the
+// device current in the calling thread, one device.
+static std::vector<int> env_devices() {
+    std::vector<int> d;
+    const char* e = getenv("GPIS_DEVICES");
+    if (!e || !*e) return d;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess) return d;
+    const char* p = e;
+    while (*p) {
+        char* end = nullptr;
+        long v = strtol(p, &end, 10);
+        if (end == p) break;
+        if (v < 0 || v >= ndev) { fprintf(stderr, "[gpismap_amd] GPIS_DEVICES: device %ld out of range (%d visible): ignored\n", v, ndev); d.clear(); return d; }
+        d.push_back((int)v);
+        p = end;
+        while (*p == ',' || *p == ' ') ++p;
+    }
+    return d;
+}
+static GPisMap3::Impl* make_impl(const GPisMap3Param& par, const camParam& c, const std::vector<int>& devs) {
+    GPisMap3::Impl* m;
+    {
+        DeviceScope ds(devs.empty() ? -1 : devs[0]);
+        m = new GPisMap3::Impl(par, c);
+    }
+    if (devs.size() > 1) {
+        std::vector<int> one(1);
+        for (size_t i = 1; i < devs.size(); ++i) {
+            one[0] = devs[i];
+            GPisMap3* peer = gpis3_impl_create_on(par, c, one.data(), 1);
+            if (!peer) break;
+            m->peers.push_back(peer);
+        }
+        const int world = 1 + (int)m->peers.size();
+        m->shard_rank = 0; m->shard_world = world;
+        for (int r = 1; r < world; ++r) { m->peers[r - 1]->impl()->shard_rank = r; m->peers[r - 1]->impl()->shard_world = world; }
+    }
+    return m;
+}
+GPisMap3::GPisMap3() : p_(make_impl(GPisMap3Param(), camParam(), env_devices())) {}
+GPisMap3::GPisMap3(GPisMap3Param par) : p_(make_impl(par, camParam(), env_devices())) {}
+GPisMap3::GPisMap3(GPisMap3Param par, camParam c) : p_(make_impl(par, c, env_devices())) {}
 GPisMap3::~GPisMap3() {
+    for (GPisMap3* q : p_->peers) delete q;
+    p_->peers.clear();
     DeviceScope dev_scope_(p_->device);
     delete p_;
 }
+// explicit device list (C-ABI gpis3_create_multi); n = 1: one map on that device, GPIS_DEVICES not consulted
+GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, const int* devices, int n) {
+    int ndev = 0;
+    if (!devices || n < 1 || hipGetDeviceCount(&ndev) != hipSuccess) return nullptr;
+    std::vector<int> devs(devices, devices + n);
+    for (int d : devs) if (d < 0 || d >= ndev) return nullptr;
+    try { return new GPisMap3(par, c, devs.data(), n); } catch (...) { return nullptr; }
+}
+GPisMap3::GPisMap3(GPisMap3Param par, camParam c, const int* devices, int n)
+    : p_(make_impl(par, c, std::vector<int>(devices, devices + n))) {}
+
+template <class F>
+static void for_each_rank(GPisMap3::Impl& m, F f) {     // rank r on its own host thread (rank 0 on the caller's)
+    const int world = 1 + (int)m.peers.size();
+    std::vector<std::thread> th;
+    for (int r = 1; r < world; ++r) th.emplace_back([&, r] { f(r, m.peers[r - 1]); });
+    f(0, (GPisMap3*)nullptr);
+    for (auto& t : th) t.join();
+}
 
 void GPisMap3::reset() try {
+    for (GPisMap3* q : p_->peers) q->reset();
     DeviceScope dev_scope_(p_->device);
     p_->reset();
 } catch (const std::exception& e) { nothrow_report("GPisMap3::reset", e.what()); } catch (...) { nothrow_report("GPisMap3::reset", "unknown exception"); }
 
 void GPisMap3::resetCam(camParam c) try {  // GPisMap3.cpp:117-123
+    for (GPisMap3* q : p_->peers) q->resetCam(c);
     DeviceScope dev_scope_(p_->device);
     p_->cam = c;
     p_->vu_grid.clear();
 } catch (const std::exception& e) { nothrow_report("GPisMap3::resetCam", e.what()); } catch (...) { nothrow_report("GPisMap3::resetCam", "unknown exception"); }
 
+// The models every rank trained travel to every other rank: pack on the owner's device, hipMemcpyPeer into the receiver's
+// buffer, unpack as predict-only models, then every rank builds its cluster table.  Bytes per frame and link: a rank sends
+// its (2 K^2 + 20 K)-byte records once to each of the other n-1 ranks (synthetic scene: ~0.9 GB / n per rank and frame).
+static int exchange_models_multi(GPisMap3* self) {
+    GPisMap3::Impl& m0 = *self->impl();
+    const int world = 1 + (int)m0.peers.size();
+    auto inst = [&](int r) { return r == 0 ? self : m0.peers[r - 1]; };
+    std::vector<int> info(2 + world);
+    if (gpis3_impl_shard_info(self, info.data(), (int)info.size())) return GPIS_ERR_STATE;
+    long long stride = 256;
+    for (int r = 0; r < world; ++r) stride = std::max(stride, gpis3_impl_shard_packed_bytes(inst(r)));
+    stride = (stride + 255) / 256 * 256;
+    std::vector<int> cnt(info.begin() + 2, info.end());      // clusters trained by rank r (same on every rank)
+    std::vector<int> rc(world, GPIS_OK);
+    auto ensure = [](void*& p, size_t& cap, size_t need) -> int {
+        if (need <= cap) return GPIS_OK;
+        (void)hipFree(p); p = nullptr; cap = 0;
+        if (hipMalloc(&p, need) != hipSuccess) return GPIS_ERR_HIP;
+        cap = need;
+        return GPIS_OK;
+    };
+    for_each_rank(m0, [&](int r, GPisMap3*) {                 // pack, every rank on its device
+        GPisMap3::Impl& m = *inst(r)->impl();
+        DeviceScope ds(m.device);
+        if (cnt[r] == 0) return;
+        rc[r] = ensure(m.d_send, m.cap_send, (size_t)cnt[r] * stride);
+        if (!rc[r]) rc[r] = gpis3_impl_shard_pack(inst(r), m.d_send, stride, nullptr);
+    });
+    for (int r = 0; r < world; ++r) if (rc[r]) return rc[r];
+    for_each_rank(m0, [&](int q, GPisMap3*) {                 // receive + unpack, every rank on its device
+        GPisMap3::Impl& m = *inst(q)->impl();
+        DeviceScope ds(m.device);
+        size_t total = 0;
+        for (int r = 0; r < world; ++r) if (r != q) total += (size_t)cnt[r] * stride;
+        if (total) rc[q] = ensure(m.d_recv, m.cap_recv, total);
+        size_t off = 0;
+        for (int r = 0; r < world && !rc[q]; ++r) {
+            if (r == q || cnt[r] == 0) continue;
+            GPisMap3::Impl& src = *inst(r)->impl();
+            const size_t bytes = (size_t)cnt[r] * stride;
+            if (hipMemcpyPeer((char*)m.d_recv + off, m.device, src.d_send, src.device, bytes) != hipSuccess) { rc[q] = GPIS_ERR_HIP; break; }
+            rc[q] = gpis3_impl_shard_unpack(inst(q), r, (char*)m.d_recv + off, cnt[r], stride, nullptr);
+            off += bytes;
+        }
+        if (!rc[q]) rc[q] = gpis3_impl_shard_finish(inst(q));
+    });
+    for (int r = 0; r < world; ++r) if (rc[r]) return rc[r];
+    return GPIS_OK;
+}
+
 void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) try {  // GPisMap3.cpp:218-237
+    if (p_->peers.empty() || p_->shard_rank != 0) { update_one(dataz, N, pose); return; }
+    // several devices: the same update on every rank (own host thread), then the exchange of the trained models
+    for_each_rank(*p_, [&](int r, GPisMap3* q) { if (r == 0) update_one(dataz, N, pose); else q->update_one(dataz, N, pose); });
+    int rc = p_->upd_rc;
+    for (GPisMap3* q : p_->peers) if (!rc) rc = q->impl()->upd_rc;
+    if (!rc && p_->table_pending) rc = exchange_models_multi(this);
+    if (rc) { p_->upd_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::update (%d devices): failed (%d)\n", 1 + (int)p_->peers.size(), rc); }
+} catch (const std::exception& e) { nothrow_report("GPisMap3::update", e.what()); p_->upd_rc = GPIS_ERR_STATE; } catch (...) { nothrow_report("GPisMap3::update", "unknown exception"); p_->upd_rc = GPIS_ERR_STATE; }
+
+void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.upd_rc = 0;
+    m.shard_jobs.clear();       // an update that returns early (no valid pixel, failed regression) must not leave the
+    m.table_pending = false;    // previous frame's job list to a later exchange
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
     m.tree.recycle();
     auto t0 = std::chrono::steady_clock::now();
@@ -751,6 +898,37 @@ bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_st
 } catch (const std::exception& e) { nothrow_report("GPisMap3::testDevice", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::testDevice", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
 bool GPisMap3::test(float* x, int dim, int leng, float* res) try {  // GPisMap3.cpp:904-949
+    if (p_->peers.empty() || p_->shard_rank != 0 || x == 0 || dim != 3 || leng < 1) return test_one(x, dim, leng, res);
+    // several devices: blocks of kQueryBlock queries dealt round-robin (GPisMap3.cpp:904-949 partitions over host threads)
+    Impl& m0 = *p_;
+    const int world = 1 + (int)m0.peers.size(), B = Impl::kQueryBlock;
+    const int nblk = (leng + B - 1) / B;
+    std::vector<char> okv(world, 1);
+    std::vector<int> frc(world, 0);
+    for_each_rank(m0, [&](int r, GPisMap3* q) {
+        GPisMap3* g = r == 0 ? this : q;
+        std::vector<float> xr, rr;
+        for (int b = r; b < nblk; b += world) {
+            const int lo = b * B, hi = std::min(leng, lo + B);
+            xr.insert(xr.end(), x + (size_t)3 * lo, x + (size_t)3 * hi);
+            rr.insert(rr.end(), res + (size_t)8 * lo, res + (size_t)8 * hi);
+        }
+        if (xr.empty()) return;
+        okv[r] = g->test_one(xr.data(), 3, (int)(xr.size() / 3), rr.data()) ? 1 : 0;
+        frc[r] = g->impl()->fail_rc;
+        if (!okv[r]) return;
+        size_t off = 0;
+        for (int b = r; b < nblk; b += world) {
+            const int lo = b * B, hi = std::min(leng, lo + B);
+            std::memcpy(res + (size_t)8 * lo, rr.data() + off, sizeof(float) * 8 * (size_t)(hi - lo));
+            off += (size_t)8 * (hi - lo);
+        }
+    });
+    for (int r = 0; r < world; ++r) if (!okv[r]) { p_->fail_rc = frc[r]; return false; }
+    return true;
+} catch (const std::exception& e) { nothrow_report("GPisMap3::test", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::test", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
+
+bool GPisMap3::test_one(float* x, int dim, int leng, float* res) try {
     DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.fail_rc = 0;
@@ -800,6 +978,7 @@ void GPisMap3::getAllNodes(std::vector<float>& out) try {
 // accessors used by the C-ABI (capi.cpp)
 int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
 int gpis3_impl_device(GPisMap3* g) { return g->impl()->device; }
+int gpis3_impl_num_devices(GPisMap3* g) { return 1 + (int)g->impl()->peers.size(); }
 int gpis3_impl_set_shard(GPisMap3* g, int rank, int world) {
     GPisMap3::Impl& m = *g->impl();
     if (m.table_pending) return GPIS_ERR_STATE;
@@ -858,6 +1037,7 @@ int gpis3_impl_shard_finish(GPisMap3* g) {
 int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
     double v[21] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
@@ -868,6 +1048,7 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_profile(q, on);
     m.mq.profile = on != 0;
     m.store.profile = on != 0;
 }

@@ -83,6 +83,7 @@ private:
     int* d_tile_ = nullptr;     // [3][tile_cap]
     int tile_cap_ = 0;
     int* d_tot_ = nullptr;      // [16] totals
+    int* d_tie_ = nullptr;      // [1] queries with an exact distance tie among their nearest candidates (list: d_jq_, free at that time)
     std::vector<int> h_maxN_, h_maxLd_;   // per class: largest N and ld (LDS sizing of K4)
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
 };

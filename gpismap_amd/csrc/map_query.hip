@@ -35,7 +35,8 @@ __device__ __forceinline__ bool cell_hit(const ClusterTableView& T, int ci, cons
 template <int DIM>
 __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const float* __restrict__ x, int n,
                                                      float half, float4* __restrict__ xq4,
-                                                     int* __restrict__ cand, int* __restrict__ ncand, int cap) {
+                                                     int* __restrict__ cand, int* __restrict__ ncand, int cap,
+                                                     int* __restrict__ tie_count, int* __restrict__ tie_list) {
     int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= n) return;
     float p[3] = {x[(size_t)DIM * q], x[(size_t)DIM * q + 1], DIM == 3 ? x[(size_t)DIM * q + 2] : 0.f};
@@ -67,20 +68,56 @@ __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const f
                 ++count;
                 // sorted top-4 by (sd, ci): ci = traversal rank
                 int cj = ci; float sj = sd;
-                for (int k = 0; k < 4; ++k) {
-                    bool better = (bi[k] < 0) || (sj < bd[k]) || (sj == bd[k] && cj < bi[k]);
-                    if (better) { float ts = bd[k]; int ti = bi[k]; bd[k] = sj; bi[k] = cj; sj = ts; cj = ti; if (cj < 0) break; }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {     // (branch-free and fully unrolled: bd / bi stay in registers)
+                    const bool better = (cj >= 0) && ((bi[k] < 0) || (sj < bd[k]) || (sj == bd[k] && cj < bi[k]));
+                    const float ts = bd[k]; const int ti = bi[k];
+                    bd[k] = better ? sj : ts; bi[k] = better ? cj : ti;
+                    sj = better ? ts : sj; cj = better ? ti : cj;
                 }
             }
     // A distance tie that can change the first three entries: reproduce std::sort exactly.
-    bool tie = false;
-    {
-        int lim = count < 4 ? count : 4;
-        for (int k = 1; k < lim; ++k) tie = tie || (bd[k] == bd[k - 1]);
-    }
-    if (tie && count > 1 && count <= 128) {
-        float key[128];
-        int rk[128], v[128];
+    const bool tie = (count > 1 && bd[1] == bd[0]) || (count > 2 && bd[2] == bd[1]) || (count > 3 && bd[3] == bd[2]);
+    // (resolved by lookup_tie_kernel, which rewrites the three candidates of the listed queries: the emulation needs
+    // ~2 KB of arrays per query, which would sit in scratch memory here)
+    if (tie && count > 1 && count <= 128) tie_list[atomicAdd(tie_count, 1)] = q;
+    int nc = count > 3 ? 3 : count;
+    ncand[q] = nc;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) cand[(size_t)k * cap + q] = (k < nc) ? T.model[bi[k]] : -1;
+}
+
+// Exact distance ties among the nearest candidates (lattice-aligned queries): the reference sorts the candidate cells
+// with std::sort (GPisMap3.cpp:826-829), whose result on equal keys depends on the algorithm -- reproduced operation by
+// operation (stdsort_emul.h).  One lane per listed query; the work arrays (candidates in traversal order, keys, the
+// permutation, the explicit recursion stack: 480 words) live in LDS, lane-interleaved.  grid = any, the list is strided.
+constexpr int kTieLanes = 32;
+template <int DIM>
+__global__ __launch_bounds__(kTieLanes) void lookup_tie_kernel(ClusterTableView T, const float* __restrict__ x, float half,
+                                                               int* __restrict__ cand, int cap,
+                                                               const int* __restrict__ tie_count, const int* __restrict__ tie_list) {
+    __shared__ float s_key[128 * kTieLanes];
+    __shared__ int s_rk[128 * kTieLanes], s_v[128 * kTieLanes], s_st[96 * kTieLanes];
+    const int lane = threadIdx.x;
+    const int ntie = *tie_count;
+    for (int e = blockIdx.x * kTieLanes + lane; e < ntie; e += gridDim.x * kTieLanes) {
+        const int q = tie_list[e];
+        float p[3] = {x[(size_t)DIM * q], x[(size_t)DIM * q + 1], DIM == 3 ? x[(size_t)DIM * q + 2] : 0.f};
+        float qlo[3], qhi[3];
+        int i0[3], i1[3];
+        const double org[3] = {T.ox, T.oy, T.oz};
+        const int gdim[3] = {T.gx, T.gy, T.gz};
+        for (int d = 0; d < 3; ++d) {
+            qlo[d] = p[d] - half; qhi[d] = p[d] + half;
+            double a = floor(((double)qlo[d] - org[d]) / T.pitch) - 1.0;
+            double b = floor(((double)qhi[d] - org[d]) / T.pitch) + 1.0;
+            a = fmax(a, 0.0); b = fmin(b, (double)(gdim[d] - 1));
+            i0[d] = (int)a; i1[d] = (int)b;
+            if (d >= DIM) { i0[d] = 0; i1[d] = 0; }
+        }
+        Strided<float> key{s_key + lane, kTieLanes};
+        Strided<int> rk{s_rk + lane, kTieLanes}, v{s_v + lane, kTieLanes};
+        Strided<int> stF{s_st + lane, kTieLanes}, stL{s_st + 32 * kTieLanes + lane, kTieLanes}, stD{s_st + 64 * kTieLanes + lane, kTieLanes};
         int n2 = 0;
         for (int iz = i0[2]; iz <= i1[2]; ++iz)
             for (int iy = i0[1]; iy <= i1[1]; ++iy)
@@ -98,13 +135,10 @@ __global__ __launch_bounds__(256) void lookup_kernel(ClusterTableView T, const f
                     ++n2;
                 }
         for (int k = 0; k < n2; ++k) v[k] = k;
-        if (stdsort_emulate(key, v, n2)) {
-            for (int k = 0; k < 3 && k < n2; ++k) bi[k] = rk[v[k]];
+        if (stdsort_emulate(key, v, n2, stF, stL, stD)) {
+            for (int k = 0; k < 3 && k < n2; ++k) cand[(size_t)k * cap + q] = T.model[rk[v[k]]];
         }
     }
-    int nc = count > 3 ? 3 : count;
-    ncand[q] = nc;
-    for (int k = 0; k < 3; ++k) cand[(size_t)k * cap + q] = (k < nc) ? T.model[bi[k]] : -1;
 }
 
 // pass-1 jobs: job j = query j, model = nearest candidate
@@ -351,7 +385,7 @@ MapQuery::MapQuery(int dim, float search_half, float var_thre, float prior_var)
 }
 
 MapQuery::~MapQuery() {
-    (void)hipFree(d_tab_); (void)hipFree(d_grid_); (void)hipFree(d_xq_); (void)hipFree(d_cand_); (void)hipFree(d_ncand_);
+    (void)hipFree(d_tab_); (void)hipFree(d_grid_); (void)hipFree(d_xq_); (void)hipFree(d_cand_); (void)hipFree(d_ncand_); (void)hipFree(d_tie_);
     (void)hipFree(d_jm_); (void)hipFree(d_jq_); (void)hipFree(d_jo_); (void)hipFree(d_out_); (void)hipFree(d_cnt_);
     (void)hipFree(d_base_); (void)hipFree(d_cursor_); (void)hipFree(d_tbase_); (void)hipFree(d_tile_); (void)hipFree(d_tot_);
     if (ev0_) (void)hipEventDestroy(ev0_);
@@ -432,6 +466,7 @@ int MapQuery::ensure_scratch(int n, int nmodels) {
         GPIS_HIP(hipMalloc(&d_xq_, sizeof(float4) * c));
         GPIS_HIP(hipMalloc(&d_cand_, sizeof(int) * 3 * c));
         GPIS_HIP(hipMalloc(&d_ncand_, sizeof(int) * c));
+        if (!d_tie_) GPIS_HIP(hipMalloc(&d_tie_, sizeof(int) * 4));
         GPIS_HIP(hipMalloc(&d_jm_, sizeof(int) * 2 * c));
         GPIS_HIP(hipMalloc(&d_jq_, sizeof(int) * 2 * c));
         GPIS_HIP(hipMalloc(&d_jo_, sizeof(int) * 2 * c));
@@ -516,10 +551,16 @@ int MapQuery::run_chunk(OnGPISStore& store, const float* d_x, int n, float* d_re
     int rc = ensure_scratch(std::max(n, 1), std::max(nmodels, 1));
     if (rc) return rc;
     const int nblk = (n + 255) / 256;
+    GPIS_HIP(hipMemsetAsync(d_tie_, 0, sizeof(int), s));
     if (dim_ == 3)
-        hipLaunchKernelGGL((lookup_kernel<3>), dim3(nblk), dim3(256), 0, s, tv_, d_x, n, search_half_, d_xq_, d_cand_, d_ncand_, cap_n_);
+        hipLaunchKernelGGL((lookup_kernel<3>), dim3(nblk), dim3(256), 0, s, tv_, d_x, n, search_half_, d_xq_, d_cand_, d_ncand_, cap_n_, d_tie_, d_jq_);
     else
-        hipLaunchKernelGGL((lookup_kernel<2>), dim3(nblk), dim3(256), 0, s, tv_, d_x, n, search_half_, d_xq_, d_cand_, d_ncand_, cap_n_);
+        hipLaunchKernelGGL((lookup_kernel<2>), dim3(nblk), dim3(256), 0, s, tv_, d_x, n, search_half_, d_xq_, d_cand_, d_ncand_, cap_n_, d_tie_, d_jq_);
+    // exact distance ties (if any): std::sort emulation, one lane per listed query, 512 workgroups striding the list
+    if (dim_ == 3)
+        hipLaunchKernelGGL((lookup_tie_kernel<3>), dim3(512), dim3(kTieLanes), 0, s, tv_, d_x, search_half_, d_cand_, cap_n_, d_tie_, d_jq_);
+    else
+        hipLaunchKernelGGL((lookup_tie_kernel<2>), dim3(512), dim3(kTieLanes), 0, s, tv_, d_x, search_half_, d_cand_, cap_n_, d_tie_, d_jq_);
     if (nmodels > 0) {
         hipLaunchKernelGGL(jobs_pass1_kernel, dim3(nblk), dim3(256), 0, s, d_cand_, d_ncand_, n, d_jm_);
         rc = eval_pass(store, n, 0, 0, nmodels, s);

@@ -116,6 +116,7 @@ private:
     int* d_work_ = nullptr; int cap_work_ = 0;   // K3b work list (job, block column)
     int* d_cwork_ = nullptr; int cap_cwork_ = 0; // cooperative K3: (job, g, G) per workgroup, then 2 sync ints per job
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
+    int* d_slots_ = nullptr; int cap_slots_ = 0; // pack / unpack slot list (grown on demand: no hipMalloc / hipFree per call)
     int* d_err_ = nullptr;                       // device error word of the training kernels (zeroed per batch)
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipStream_t s2_ = nullptr, s3_ = nullptr;    // side streams: the three size groups of a training batch run beside each other
@@ -176,11 +177,12 @@ struct EvalArgs {
 #define K4_QS 1   // measured on the 256^3 bench: 1 set / 128 VGPRs / 2 workgroups per CU 811 ms, 2 sets / 256 VGPRs / 1 per CU 870 ms
 #endif
 #define ONGPIS_TILE_Q (8 * K4_QS)   // queries per K4 workgroup (K4_QS sets of 8 sharing every X tile)
-#define ONGPIS_MAX_K 16384   // allocation sanity bound only (10 K^2 bytes per model)
+#define ONGPIS_MAX_K 16384   // allocation sanity bound (10 K^2 bytes per model); the binding limit is K4's LDS: ongpis_eval_fits
 __host__ __device__ inline int ongpis_class_of_nbx(int nbx) {
     return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= 16 ? 2 : (nbx <= 32 ? 3 : (nbx <= 48 ? 4 : 5))));
 }
 int ongpis_eval_class(int nbx);
+bool ongpis_eval_fits(int N, int ld);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 
 }  // namespace gpis

@@ -654,11 +654,7 @@ int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hi
     const bool small = max_nb <= 5;   // 15 tiles: two accumulator tiles per wavefront, two workgroups per CU
     const kern_t kern = small ? (kern_t)ongpis_train_fused_kernel<5, 4, 3> : (kern_t)ongpis_train_fused_kernel<8, 7, 2>;
     const size_t lds = ongpis_fused_lds_bytes(max_nb);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[small]) {
-        GPIS_HIP(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set[small] = true;
-    }
+    if (ensure_dynamic_lds((const void*)kern, 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(njobs), dim3(kFT), lds, s, a);
     GPIS_HIP(hipGetLastError());
 #ifdef GPIS_INSTRUMENT

@@ -3,18 +3,34 @@
 // entry (K4) used by the kernel-level C-ABI and the parity tests.
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <numeric>
+#include <set>
+#include <utility>
 #include "ongpis.h"
 
 namespace gpis {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+int ensure_dynamic_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::set<std::pair<int, const void*>> done;
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return GPIS_ERR_HIP;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({dev, kernel})) return GPIS_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) { fprintf(stderr, "[gpismap_amd] hipFuncSetAttribute(device %d): %s\n", dev, hipGetErrorString(e)); return GPIS_ERR_HIP; }
+    done.insert({dev, kernel});
+    return GPIS_OK;
+}
+
 OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {}
 
 OnGPISStore::~OnGPISStore() {
     clear();
-    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_);
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_); (void)hipFree(d_slots_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (evf_) (void)hipEventDestroy(evf_);
@@ -157,8 +173,8 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
     for (int j = 0; j < nj; ++j) {
         const TrainJob& tj = jobs[j];
         int K = tj.n + dim_ * tj.ng;
-        if (K > ONGPIS_MAX_K) {
-            fprintf(stderr, "[gpismap_amd] cluster with K=%d exceeds the supported size (%d): previous model kept\n", K, ONGPIS_MAX_K);
+        if (K > ONGPIS_MAX_K || !ongpis_eval_fits(tj.n, (int)align_up((size_t)K + 1, 32))) {
+            fprintf(stderr, "[gpismap_amd] cluster with N=%d, K=%d exceeds what the prediction kernel can stage in LDS (4 ld + 16 N bytes + two B blocks <= 158 KB; K <= %d): previous model kept\n", tj.n, K, ONGPIS_MAX_K);
             if (!deferred_rc) deferred_rc = GPIS_ERR_LIMIT;
             continue;
         }
@@ -219,7 +235,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     while (n0 < nj && tab[4 * n0 + 2] + dim_ * tab[4 * n0 + 3] > 256) ++n0;
     // cooperative group: G workgroups ~ nb^2 (work nb^3 over a critical path of nb steps), one workgroup per CU, at most
     // kCoopMaxWG in the launch so that all of them are resident at once
-    // Measured on the synthetic frames (GPIS_K3_TUNE builds read these from the environment): below ~32 block rows one
+    // Measured on the synthetic frames (instrumented builds read these from the environment: ongpis_store_instr.inc): below ~32 block rows one
     // workgroup per cluster is faster; few workgroups per cluster (so that MANY clusters fit the launch) beat many workgroups
     // for few clusters -- a cooperative cluster is bound by its serial path, and every large cluster left to the
     // one-workgroup kernel costs more than a small G costs the largest ones.
@@ -227,11 +243,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     if (!coop_capacity) coop_capacity = std::max(2, ongpis_coop_capacity());
     int kCoopMinNb = 32, kCoopMaxWG = coop_capacity;
     int kCoopGDiv = 900, kCoopGMax = 6;
-#ifdef GPIS_K3_TUNE
-    if (const char* e = getenv("K3_MINNB")) kCoopMinNb = atoi(e);
-    if (const char* e = getenv("K3_MAXWG")) kCoopMaxWG = atoi(e);
-    if (const char* e = getenv("K3_GDIV")) kCoopGDiv = atoi(e);
-    if (const char* e = getenv("K3_GMAX")) kCoopGMax = atoi(e);
+#ifdef GPIS_INSTRUMENT
+#include "ongpis_store_instr.inc"   // schedule knobs from the environment (tuning sweeps only)
 #endif
     int ncoop = 0;
     std::vector<int> cwork;
@@ -243,7 +256,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         for (int g = 0; g < G; ++g) { cwork.push_back(j); cwork.push_back(g); cwork.push_back(G); }
         ncoop = j + 1;
     }
-#ifdef GPIS_UPDATE_TRACE
+#ifdef GPIS_INSTRUMENT
     {   // size profile of the batch: block rows per cluster, by group
         int hist[3][12] = {};
         for (int j = 0; j < nj; ++j) {
@@ -436,49 +449,100 @@ size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
     return mx;
 }
 
+// Records of models that are NOT trained (allocation failure, refused size) travel as "absent" records -- a header with
+// K = 0 -- so that every rank still reaches the collective and the receivers mark those slots untrained.
 int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s) {
     if (n <= 0) return GPIS_OK;
+    if (stride % 256 != 0) return GPIS_ERR_ARG;
+    std::vector<int> present, pidx;
     for (int i = 0; i < n; ++i) {
         const ClusterModel* m = model(slots[i]);
-        if (!m || !m->base || !m->Xt || packed_model_bytes(m->ld, m->N) > stride) return GPIS_ERR_ARG;
+        if (m && m->base && m->Xt) {
+            if (packed_model_bytes(m->ld, m->N) > stride) return GPIS_ERR_ARG;
+            present.push_back(slots[i]); pidx.push_back(i);
+        }
     }
     int rc = sync_models(s);
     if (rc) return rc;
-    int* d_slots = nullptr;
-    GPIS_HIP(hipMalloc(&d_slots, sizeof(int) * (size_t)n));
-    GPIS_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-    model_pack_launch(true, d_models_, d_slots, n, (char*)d_buf, stride, s);
-    GPIS_HIP(hipGetLastError());
+    if ((int)present.size() < n) {      // absent records: zero headers (K = 0)
+        for (int i = 0; i < n; ++i) {
+            const ClusterModel* m = model(slots[i]);
+            if (!(m && m->base && m->Xt)) GPIS_HIP(hipMemsetAsync((char*)d_buf + (size_t)i * stride, 0, 64, s));
+        }
+    }
+    if (!present.empty()) {
+        if (n > cap_slots_) {
+            (void)hipFree(d_slots_); d_slots_ = nullptr;
+            GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * (size_t)(n + n / 2 + 64)));
+            cap_slots_ = n + n / 2 + 64;
+        }
+        // the kernel packs record blockIdx of the list it is given: pack the present models record by record position
+        if ((int)present.size() == n) {
+            GPIS_HIP(hipMemcpyAsync(d_slots_, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+            model_pack_launch(true, d_models_, d_slots_, n, (char*)d_buf, stride, s);
+        } else {
+            for (size_t k = 0; k < present.size(); ++k) {       // rare path: one launch per present record
+                GPIS_HIP(hipMemcpyAsync(d_slots_, &present[k], sizeof(int), hipMemcpyHostToDevice, s));
+                model_pack_launch(true, d_models_, d_slots_, 1, (char*)d_buf + (size_t)pidx[k] * stride, stride, s);
+                GPIS_HIP(hipStreamSynchronize(s));
+            }
+        }
+        GPIS_HIP(hipGetLastError());
+    }
     GPIS_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d_slots);
     return GPIS_OK;
 }
 
 int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slots, hipStream_t s) {
     if (n <= 0) return GPIS_OK;
+    if (stride % 256 != 0) return GPIS_ERR_ARG;
     std::vector<int> hdr((size_t)16 * n);
     GPIS_HIP(hipMemcpy2DAsync(hdr.data(), 64, d_buf, stride, 64, (size_t)n, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
+    std::vector<int> created;            // slots made by this call: released again if a later record is refused
+    auto bail = [&](int rc) { for (int sl : created) release_slot(sl); return rc; };
+    std::vector<int> present, pidx;
     for (int i = 0; i < n; ++i) {
         const int* h = &hdr[(size_t)16 * i];
         const int dim = h[0], N = h[1], ng = h[2], K = h[3], ld = h[4];
-        if (dim != dim_ || N <= 0 || ng < 0 || ng > N || K != N + dim * ng || ld != (int)align_up((size_t)K + 1, 32) ||
-            packed_model_bytes(ld, N) > stride)
-            return GPIS_ERR_ARG;
-        if (slots[i] < 0) slots[i] = new_slot();
-        else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return GPIS_ERR_ARG;
+        const bool absent = (K == 0 && N == 0);
+        if (!absent && (dim != dim_ || N <= 0 || ng < 0 || ng > N || K != N + dim * ng || ld != (int)align_up((size_t)K + 1, 32) ||
+                        packed_model_bytes(ld, N) > stride))
+            return bail(GPIS_ERR_ARG);
+        if (slots[i] < 0) { slots[i] = new_slot(); created.push_back(slots[i]); }
+        else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return bail(GPIS_ERR_ARG);
+        if (absent) {                    // the owner could not train it: untrained here too (test() sees no GP in that cell)
+            ClusterModel& m = models_[slots[i]];
+            if (m.base) pool_free(pool_, m.base);
+            std::memset(&m, 0, sizeof(ClusterModel));
+            dirty_ = true;
+            continue;
+        }
         int rc = alloc_model(slots[i], N, ng, kAllocPredictOnly);
-        if (rc) return rc;
+        if (rc) return bail(rc);
+        present.push_back(slots[i]); pidx.push_back(i);
     }
     int rc = sync_models(s);
-    if (rc) return rc;
-    int* d_slots = nullptr;
-    GPIS_HIP(hipMalloc(&d_slots, sizeof(int) * (size_t)n));
-    GPIS_HIP(hipMemcpyAsync(d_slots, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-    model_pack_launch(false, d_models_, d_slots, n, (char*)const_cast<void*>(d_buf), stride, s);
-    GPIS_HIP(hipGetLastError());
+    if (rc) return bail(rc);
+    if (!present.empty()) {
+        if (n > cap_slots_) {
+            (void)hipFree(d_slots_); d_slots_ = nullptr;
+            GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * (size_t)(n + n / 2 + 64)));
+            cap_slots_ = n + n / 2 + 64;
+        }
+        if ((int)present.size() == n) {
+            GPIS_HIP(hipMemcpyAsync(d_slots_, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+            model_pack_launch(false, d_models_, d_slots_, n, (char*)const_cast<void*>(d_buf), stride, s);
+        } else {
+            for (size_t k = 0; k < present.size(); ++k) {
+                GPIS_HIP(hipMemcpyAsync(d_slots_, &present[k], sizeof(int), hipMemcpyHostToDevice, s));
+                model_pack_launch(false, d_models_, d_slots_, 1, (char*)const_cast<void*>(d_buf) + (size_t)pidx[k] * stride, stride, s);
+                GPIS_HIP(hipStreamSynchronize(s));
+            }
+        }
+        GPIS_HIP(hipGetLastError());
+    }
     GPIS_HIP(hipStreamSynchronize(s));
-    (void)hipFree(d_slots);
     return GPIS_OK;
 }
 

@@ -35,10 +35,13 @@ namespace gpis {
 typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const int __attribute__((address_space(1))) * giptr;
 
-// Ablation builds for tools/k4_ablate.sh only (-DK4X=<bits>; results are WRONG when set): 1 = generate only the
-// first chunks (prologue), 16 = one X tile load per row and chunk, 32 = B operands from registers (no LDS reads), 4 / 8 unused
-#ifndef K4X
-#define K4X 0
+// Instrumented builds only (make EXTRA=-DGPIS_INSTRUMENT): per-workgroup cycle stamps, ongpis_test_instr.inc.  The
+// timing ablations of round 2 (wrong results by construction) are gone from the source; their findings are in DESIGN.md.
+#ifdef GPIS_INSTRUMENT
+#include "ongpis_test_instr.inc"
+#else
+#define K4_TRACE_DECL(A)
+#define K4_STAMP() do {} while (0)
 #endif
 #ifndef K4_MINW
 #define K4_MINW (K4_QS == 1 ? 4 : 2)   // wavefronts per SIMD the register budget is cut for (128 / 256 VGPRs)
@@ -87,13 +90,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     const int joff = A.tile_off[tile], jcnt = A.tile_cnt[tile];   // 1..16 queries
     const int nset = (QS == 2 && jcnt > 8) ? 2 : 1;
     const int CB = A.cb, NSLOT = A.nslot;
-#if K4X & 64
-    unsigned long long* trc = (A.trace && blockIdx.x % 997 == 0 && blockIdx.x / 997 < 64) ? A.trace + (blockIdx.x / 997) * 64 + wave * 8 : nullptr;
-    int tri = 0;
-#define K4_STAMP() do { if (trc && lane == 0 && tri < 8) trc[tri++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define K4_STAMP() do {} while (0)
-#endif
+    K4_TRACE_DECL(A)
     K4_STAMP();
 
     // LDS carve (all dynamic, 16-byte aligned pieces)
@@ -236,15 +233,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     const bool two = (QS == 2) && (nset == 2);
     auto mfma_tile = [&](f32x16& acc0, f32x16& acc1, const float (&av)[16], const float* Bt) {
         const float* Bl = Bt + h * kTileStride + l31;
-        if (K4X & 32) {   // ablation: B operands from registers
-            const float bq = Bl[0];
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq, acc0, 0, 0, 0);
-                if (QS == 2) { if (two) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bq + 1.f, acc1, 0, 0, 0); }
-            }
-            return;
-        }
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], Bl[kk * 2 * kTileStride], acc0, 0, 0, 0);
@@ -291,7 +279,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                     for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
 
             for (int ci = 0; ci < nch; ++ci, ++gci) {
-                if (WP == 0 && gen_first && !(K4X & 1)) produce_next();
+                if (WP == 0 && gen_first) produce_next();
                 {
                     if (K4_PRIO) __builtin_amdgcn_s_setprio(K4_PRIO);
                     const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
@@ -313,11 +301,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                             load_a(av[0], b, c0);
 #pragma unroll 1
                             for (int c = c0; c <= cend; c += 2) {
-                                if (c + 1 <= cend && !(K4X & 16)) load_a(av[1], b, c + 1);
+                                if (c + 1 <= cend) load_a(av[1], b, c + 1);
                                 mfma_tile(acc[t][0], acc[t][QS - 1], av[0], buf + (size_t)(c - c0) * QS * kTileFloats);
                                 if (c + 1 <= cend) {
-                                    if (c + 2 <= cend && !(K4X & 16)) load_a(av[0], b, c + 2);
-                                    mfma_tile(acc[t][0], acc[t][QS - 1], av[(K4X & 16) ? 0 : 1], buf + (size_t)(c + 1 - c0) * QS * kTileFloats);
+                                    if (c + 2 <= cend) load_a(av[0], b, c + 2);
+                                    mfma_tile(acc[t][0], acc[t][QS - 1], av[1], buf + (size_t)(c + 1 - c0) * QS * kTileFloats);
                                 }
                             }
 #endif
@@ -325,7 +313,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                     }
                 }
                 if (K4_PRIO) __builtin_amdgcn_s_setprio(0);
-                if (WP == 0 && !gen_first && !(K4X & 1)) produce_next();
+                if (WP == 0 && !gen_first) produce_next();
                 __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
             }
             // sums of squares of the finished rows; row K (block nbx-1: group 0, slot 0, wave 0) is the mean
@@ -374,7 +362,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         }
     }
     K4_STAMP();
-#undef K4_STAMP
 }
 
 // Size classes by nbx = ceil((K+1)/32): W wavefronts per workgroup (ongpis.h, ongpis_class_of_nbx).
@@ -425,40 +412,13 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
         {ongpis_eval_kernel<1, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, true, kQS, K4_NBW, 0>,
          ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW, K4_WP3>}};
     const int kidx = wclass < 3 ? wclass : 3;
-    static bool attr_set = false;
-    if (!attr_set) {
-        attr_set = true;
-        for (int t = 0; t < 2; ++t)
-            for (int i = 0; i < 4; ++i) {
-                const hipError_t e = hipFuncSetAttribute((const void*)kern[t][i], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                if (e != hipSuccess) fprintf(stderr, "[gpismap_amd] K4 kernel %d/%d: hipFuncSetAttribute: %s\n", t, i, hipGetErrorString(e));
-            }
-    }
-#if K4X & 64
-    static unsigned long long* d_trace = nullptr;
-    if (!d_trace) { (void)hipMalloc(&d_trace, sizeof(unsigned long long) * 64 * 64); }
-    (void)hipMemsetAsync(d_trace, 0, sizeof(unsigned long long) * 64 * 64, s);
-    args.trace = d_trace;
+    if (ensure_dynamic_lds((const void*)kern[use_table][kidx], 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
+#ifdef GPIS_INSTRUMENT
+    k4_trace_arm(args, s);
 #endif
     hipLaunchKernelGGL(kern[use_table][kidx], dim3(ntiles), dim3(64 * W), lds, s, args);
-#if K4X & 64
-    {
-        (void)hipStreamSynchronize(s);
-        static unsigned long long hb[64 * 64];
-        (void)hipMemcpy(hb, d_trace, sizeof(hb), hipMemcpyDeviceToHost);
-        FILE* f = fopen("gpurun_out/k4_trace.txt", "w");
-        if (f) {
-            for (int g = 0; g < 64; ++g) {
-                if (!hb[g * 64]) continue;
-                for (int w = 0; w < 8; ++w) {
-                    fprintf(f, "wg %d wave %d:", g, w);
-                    for (int i = 0; i < 8; ++i) if (hb[g * 64 + w * 8 + i]) fprintf(f, " %llu", hb[g * 64 + w * 8 + i] - hb[g * 64]);
-                    fprintf(f, "\n");
-                }
-            }
-            fclose(f);
-        }
-    }
+#ifdef GPIS_INSTRUMENT
+    k4_trace_dump(s);
 #endif
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {
@@ -470,5 +430,14 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
 }
 
 int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }
+
+// Can K4 hold a cluster of N points / leading dimension ld?  It stages the row table and the points in LDS beside a
+// two-slot ring of at least one column block each (the exp table is optional).  Asked at TRAINING time: a cluster that
+// could be factorised but never evaluated is refused there (GPIS_ERR_LIMIT, the previous model is kept).
+bool ongpis_eval_fits(int N, int ld) {
+    const int W = kClassW[ongpis_class_of_nbx(ld / 32)];
+    const size_t blk = kQS * sizeof(float) * kTileFloats;
+    return eval_lds_fixed(W, N, ld, 0) + 2 * blk <= (size_t)158 * 1024;
+}
 
 }  // namespace gpis

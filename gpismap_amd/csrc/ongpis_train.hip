@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void ongpis_gather_kernel(const ClusterModel* 
                                                             const float* __restrict__ pts, int cap) {
     __shared__ int cnt[256];
     const int job = blockIdx.x, tid = threadIdx.x;
-    const ClusterModel m = models[JOB_MODEL(job)];
+    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int off = JOB_OFF(job), N = m.N, dim = m.dim, ng = m.ng;
     const int chunk = (N + 255) / 256;
     const int k0 = tid * chunk, k1 = min(N, k0 + chunk);
@@ -91,7 +91,7 @@ __device__ __forceinline__ void putL(float* L, int ld, int r, int c, float v) {
 __global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel* __restrict__ models,
                                                              const int* __restrict__ d_jobs) {
     const int job = blockIdx.x, tid = threadIdx.x;
-    const ClusterModel m = models[JOB_MODEL(job)];
+    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int N = m.N, ng = m.ng, dim = m.dim, K = m.K, ld = m.ld;
     float* L = m.L;
     const float a = (float)(sqrt(3.0) / (double)m.scale);  // covFnc.cpp:147
@@ -267,13 +267,19 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile offsets stay scalar (no waterfall loops around the buffer loads)
     const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel m = models[JOB_MODEL(job)];
+    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
     const int nbr = ld / 32;           // block rows (ld = 32*ceil((K+1)/32)): includes the block holding row K
     const int ntl = nbr * (nbr + 1) / 2;
     const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
+    // The column-major factor through a buffer resource: element (row, col) = lane part (row within the tile, the lane
+    // half's column offset 4h) in ONE VGPR + a scalar offset per column.  With plain pointers the 16 column addresses
+    // of a tile (and the 32 of the diagonal block) are 64-bit VGPR pairs that get hoisted and spilled.
+    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
+    const int Lvoff = (l31 + 4 * h * ld) * 4;
+    auto tile_soff = [&](int bi, int jc, int r) { return (unsigned)((bi * 32 + (size_t)(jc * 32 + (r & 3) + 8 * (r >> 2)) * ld) * 4); };
 
     // Lt(b, c) in A-operand order.  The tiles hold -L; SIGN flips them back on load (0x80000000) or not (0).
     auto load_tile = [&](float (&o)[16], int b, int c, unsigned sign) {
@@ -286,14 +292,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
         }
     };
 
-#ifdef K3_TRACE
-    __shared__ long long stamps[256];
-    int nst = 0;
-#define K3_STAMP() do { if (blockIdx.x == 7 && tid == 0 && nst < 256) stamps[nst++] = __builtin_readcyclecounter(); } while (0)
-#else
-#define K3_STAMP() do {} while (0)
-#endif
-    K3_STAMP();
     for (int j = 0; j < nb; ++j) {
         const int pw = min(32, K - 32 * j);
         // Tile rows of block column j -> wavefronts.  With 8 wavefronts, wave 0 takes ONLY the diagonal tile and the others
@@ -313,15 +311,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                 const int bi = tile_row(t0 + tt);
                 act[tt] = bi < nbr;
                 if (act[tt]) {
-                    const float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[tt][r] = Cb[(size_t)rowmap_t(r, h) * ld];
+                    for (int r = 0; r < 16; ++r) acc[tt][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
                 } else {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[tt][r] = 0.f;
                 }
             }
-            K3_STAMP();   // A: accumulators loaded
             if (act[0]) {
                 // Panel operands: a_ = -L(j, p) (sign flipped at the matrix instruction), bq = -L(bi, p).  The
                 // panel loop is blocked by PB: every load of a trip is issued AND consumed inside it (fully
@@ -357,7 +353,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                     }
                 }
             }
-            K3_STAMP();   // B: panel products done
             // ---- diagonal tile: wave 0, first round
             if (t0 == 0) {
                 if (wave == 0) {
@@ -380,13 +375,13 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
 #pragma unroll
                             for (int c = 0; c < 32; ++c) {
                                 Lc[c * 32 + lane] = a[c];
-                                if (c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = a[c];
+                                if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[c]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
                             }
                         }
                     } else {
                         // Partial last block (once per cluster): same operations through LDS; rows >= pw (the y row K
                         // and the padding) are carried along as rows of the matrix.
-                        volatile float* Dv = D;
+                        volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
                         for (int c = 0; c < pw; ++c) {
                             float d = sqrtf(Dv[c * 33 + c]);
                             float lij = 0.f;
@@ -413,7 +408,6 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                 }
                 __syncthreads();
             }
-            K3_STAMP();   // C: diagonal factorised
             // ---- other tiles: X = T L_jj^{-T}, then store column-major and re-tiled
 #pragma unroll
             for (int tt = 0; tt < NT; ++tt) {
@@ -432,9 +426,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                 }
                 if (act[tt] && bi != j) {
                     diag_solve32<true>(acc[tt], Lc, h);
-                    float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Cb[(size_t)rowmap_t(r, h) * ld] = acc[tt][r];
+                    for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[tt][r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
                     {
                         float* T = Tt[wave];
 #pragma unroll
@@ -456,17 +449,10 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol
                 }
             }
         }
-        K3_STAMP();   // D: tiles solved and stored
         __syncthreads();   // column j complete: Lt tiles visible, Lc reusable
     }
 
-    K3_STAMP();
     chol_epilogue<64 * NW>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
-    K3_STAMP();
-#ifdef K3_TRACE
-    if (blockIdx.x == 7 && tid == 0) { for (int i = 1; i < nst; ++i) printf("%d:%lld ", i, stamps[i] - stamps[i - 1]); printf("\nK=%d nb=%d total %lld\n", K, nb, stamps[nst - 1] - stamps[0]); }
-#endif
-#undef K3_STAMP
 }
 
 
@@ -505,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel m = models[JOB_MODEL(job)];
+    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
     const int nbr = ld / 32;
@@ -517,6 +503,9 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     int* alldone = sync + 2 * job + 1;   // workgroups that have finished their rows
     const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
     const bool inject = (ctl[1] & 1) != 0;
+    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
+    const int Lvoff = (l31 + 4 * h * ld) * 4;
+    auto tile_soff = [&](int bi, int jc, int r) { return (unsigned)((bi * 32 + (size_t)(jc * 32 + (r & 3) + 8 * (r >> 2)) * ld) * 4); };
     auto load_tile = [&](float (&o)[16], int b, int c) {
         const int sbase = tri_index(b, c) * 4096;
 #pragma unroll
@@ -557,10 +546,10 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             if (wave == 0) {
                 // (device-scope loads: the block was modified by other wavefronts of this CU after it was last read here, and
                 // the vector L1 is not refreshed by stores)
-                float* Cb = L + (size_t)(j * 32 + l31) + (size_t)(j * 32) * ld;
+                // (aux 16 = sc1: the device-scope load of the agent-relaxed atomic this replaces -- served by L2, not the CU's L1)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    D[l31 * 33 + rowmap_t(r, h)] = __hip_atomic_load(Cb + (size_t)rowmap_t(r, h) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    D[l31 * 33 + rowmap_t(r, h)] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 if (pw == 32) {
@@ -573,11 +562,11 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 #pragma unroll
                         for (int c = 0; c < 32; ++c) {
                             Lc[c * 32 + lane] = a[c];
-                            if (c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = a[c];
+                            if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[c]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
                         }
                     }
                 } else {
-                    volatile float* Dv = D;
+                    volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
                     for (int c = 0; c < pw; ++c) {
                         float d = sqrtf(Dv[c * 33 + c]);
                         float lij = 0.f;
@@ -634,11 +623,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
         __syncthreads();
         for (int bi = first + wave * G; bi < nbr; bi += NW * G) {
             f32x16 acc;
-            {
-                const float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = Cb[(size_t)rowmap_t(r, h) * ld];
-            }
+            for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
             if (j > 0) {
                 float a_[2][16], bq[2][16];
                 load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
@@ -655,9 +641,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 }
             }
             diag_solve32<true>(acc, Lc, h);
-            float* Cb = L + (size_t)(bi * 32 + l31) + (size_t)(j * 32) * ld;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Cb[(size_t)rowmap_t(r, h) * ld] = acc[r];
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
             float* T = Tt[wave];
 #pragma unroll
             for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
@@ -677,14 +662,13 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             }
             __builtin_amdgcn_wave_barrier();
             if (bi < nb) {     // incremental diagonal of row bi: A(bi,bi) -= L(bi,j) L(bi,j)^T (rows without a pivot have none)
-                float* Db = L + (size_t)(bi * 32 + l31) + (size_t)(bi * 32) * ld;
                 f32x16 dacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dacc[r] = __hip_atomic_load(Db + (size_t)rowmap_t(r, h) * ld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) Db[(size_t)rowmap_t(r, h) * ld] = dacc[r];
+                for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
             }
         }
     }
@@ -717,6 +701,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 // the 8 wavefronts of a workgroup round-robin; row b still needs every earlier row of the column, so the wavefronts run as
 // a software pipeline -- each accumulates its row over the rows already published (LDS counter `rowdone`, tiles travel
 // through Zt in L2) and waits only for the last few.  The chain of a row is unchanged (ascending p, k): same bits.
+constexpr int kRowAbort = -(1 << 30);   // K3b row counter value meaning "a wavefront of this column gave up" (the counter starts at c - 1 >= -1)
 constexpr int kShortRows = 8;   // K3b: columns with at most this many block rows keep their transposed tiles in registers
 constexpr int kShortWaves = 8;  // ... and are run kShortWaves adjacent columns per workgroup (one wavefront each): the columns
                                 // of a cluster read the same Lt tiles at about the same time, so the CU's L1 serves the repeats
@@ -724,7 +709,7 @@ constexpr int kMidWaves = 8;    // the one-wavefront columns of the larger clust
 // NWI = 8: one long column per workgroup, 8 pipelined wavefronts.  NWI = 1: one wavefront per column, kMidWaves (REGZ:
 // kShortWaves) adjacent columns of one cluster per workgroup; the work entry names the first of them.
 template <int NWI, bool REGZ>
-__global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)), REGZ ? 3 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
+__global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)), REGZ ? 2 : 1) void ongpis_inv_kernel(const ClusterModel* __restrict__ models,
                                                                const int* __restrict__ d_jobs, const int* __restrict__ work,
                                                                int* __restrict__ ctl) {
     __shared__ __attribute__((aligned(16))) float Tall[REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : NWI)][32 * 36];
@@ -737,7 +722,7 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
     const int wave = (NWI == 1) ? 0 : wave_id;                     // position inside the column's team
     const int job = work[2 * blockIdx.x];
     const int c = work[2 * blockIdx.x + 1] + (NWI == 1 ? wave_id : 0);
-    const ClusterModel m = models[JOB_MODEL(job)];
+    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int K = m.K, nb = m.nb, nbx = m.ld / 32;
     if (NWI == 1 && c >= nb) return;
     const int ntl = nbx * (nbx + 1) / 2;
@@ -790,7 +775,7 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
         if (NWI > 1) {
             __builtin_amdgcn_s_waitcnt(0x0f70);    // vmcnt(0)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            if (lane == 0 && *rowdone >= 0) *rowdone = b;
+            if (lane == 0 && *rowdone > kRowAbort) *rowdone = b;
         }
     };
     auto times_inverse = [&](const f32x16& sacc, int b) {   // inv(L_bb) * S, S = accumulator tile as the B operand
@@ -895,20 +880,20 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
             if (NWI > 1) {
                 // rows of the column appear in order (LDS counter).  The wait is bounded by the 100 MHz clock; on expiry --
                 // a protocol error, the rows are published by this very workgroup -- bit 2 of the error word is set and the
-                // wavefront abandons its rows (never re-accumulating: p only moves forward); a negative counter tells the
-                // other wavefronts of the column to stop as well.
+                // wavefront abandons its rows (never re-accumulating: p only moves forward); the counter at kRowAbort tells
+                // the other wavefronts of the column to stop as well.
                 int avail = *rowdone;
                 const long long t0 = wall_clock64();
-                while (avail >= 0 && avail < p) {
+                while (avail > kRowAbort && avail < p) {
                     if (wall_clock64() - t0 > (ctl[2] > 0 ? (long long)ctl[2] : 200000000LL)) {
-                        if (lane == 0) { atomicOr(ctl, 4); *rowdone = -1; }
-                        avail = -1;
+                        if (lane == 0) { atomicOr(ctl, 4); *rowdone = kRowAbort; }
+                        avail = kRowAbort;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(1);
                     avail = *rowdone;
                 }
-                if (avail < 0) return;
+                if (avail <= kRowAbort) return;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 pe = min(avail, b - 1);
             }

@@ -13,14 +13,23 @@ namespace gpis {
 // reference sorts candidate cells by squared centre distance with std::sort
 // (GPisMap3.cpp:826-829); with exact distance ties (lattice-aligned queries) the outcome depends
 // on this algorithm, so the tie path reproduces it operation by operation.
+// key / v / the explicit recursion stack are array VIEWS (anything with operator[]: plain pointers on the host and in
+// private memory, Strided<> over a lane-interleaved LDS block in the device tie kernel).
+template <class T>
+struct Strided {
+    T* p; int stride;
+    GPIS_HD T& operator[](int i) const { return p[(size_t)i * stride]; }
+};
 #define CMP(a, b) (key[(a)] < key[(b)])
-GPIS_HD inline void unguarded_linear_insert(const float* key, int* v, int last) {
+template <class KA, class VA>
+GPIS_HD inline void unguarded_linear_insert(KA key, VA v, int last) {
     int val = v[last];
     int next = last - 1;
     while (CMP(val, v[next])) { v[last] = v[next]; last = next; --next; }
     v[last] = val;
 }
-GPIS_HD inline void insertion_sort(const float* key, int* v, int first, int last) {
+template <class KA, class VA>
+GPIS_HD inline void insertion_sort(KA key, VA v, int first, int last) {
     if (first == last) return;
     for (int i = first + 1; i != last; ++i) {
         if (CMP(v[i], v[first])) {
@@ -30,12 +39,12 @@ GPIS_HD inline void insertion_sort(const float* key, int* v, int first, int last
         } else unguarded_linear_insert(key, v, i);
     }
 }
-GPIS_HD inline bool stdsort_emulate(const float* key, int* v, int n) {
+template <class KA, class VA, class SA>
+GPIS_HD inline bool stdsort_emulate(KA key, VA v, int n, SA stF, SA stL, SA stD) {
     if (n <= 1) return true;
     int depth = 0;
     for (int t = n; t > 1; t >>= 1) ++depth;
     depth *= 2;
-    int stF[32], stL[32], stD[32];
     int sp = 0;
     stF[0] = 0; stL[0] = n; stD[0] = depth; sp = 1;
     while (sp > 0) {
@@ -75,6 +84,10 @@ GPIS_HD inline bool stdsort_emulate(const float* key, int* v, int n) {
         for (int i = 16; i < n; ++i) unguarded_linear_insert(key, v, i);
     } else insertion_sort(key, v, 0, n);
     return true;
+}
+GPIS_HD inline bool stdsort_emulate(const float* key, int* v, int n) {
+    int stF[32], stL[32], stD[32];
+    return stdsort_emulate<const float*, int*, int*>(key, v, n, stF, stL, stD);
 }
 #undef CMP
 

@@ -80,7 +80,11 @@ public:
     bool test(float* x, int dim, int leng, float* res);
     void resetCam(camParam c);
 
-    /* Extensions (not in the reference): device-resident queries and introspection. */
+    /* Extensions (not in the reference): device-resident queries, introspection, several devices behind one object
+     * (GPIS_DEVICES=0,1,... in the environment, or the device-list constructor / gpis3_create_multi). */
+    GPisMap3(GPisMap3Param par, camParam c, const int* devices, int n);
+    void update_one(float* dataz, int N, std::vector<float>& pose);   /* this object's own device only */
+    bool test_one(float* x, int dim, int leng, float* res);
     bool testDevice(const float* d_x, int leng, float* d_res, void* hip_stream);
     void getAllNodes(std::vector<float>& out9);  /* pos3 grad3 val sigx sigg, tree order */
     struct Impl;

@@ -41,6 +41,14 @@ int gpis_get_device(void);
 
 /* ---- 3-D map (GPisMap3) -------------------------------------------------- */
 void* gpis3_create(const gpis_cam* cam /* NULL = reference defaults */);
+/* ONE map object over several devices of this process (a device may be listed more than once: logical shards on one GPU).
+ * update() runs on every listed device from its own host thread, each trains its K^3-balanced share of the frame's
+ * clusters, the packed models are copied device to device and every device ends up with the whole map; test() deals the
+ * queries to the devices in blocks of 65 536 and answers them concurrently.  Results are bit-identical to a one-device
+ * map.  The GPisMap3 class does the same when GPIS_DEVICES=0,1,... is set in the environment (so the unchanged mex
+ * gateway uses every GPU).  Reference: the fan-out over host threads, GPisMap3.cpp:759-784 (updateGPs), :904-949 (test). */
+void* gpis3_create_multi(const gpis_cam* cam /* NULL = reference defaults */, const int* devices, int n);
+int   gpis3_num_devices(void* map);
 void  gpis3_destroy(void* map);
 int   gpis3_reset(void* map);                                   /* GPisMap3::reset    GPisMap3.cpp:99  */
 int   gpis3_set_camera(void* map, const gpis_cam* cam);         /* GPisMap3::resetCam GPisMap3.cpp:117 */

@@ -250,3 +250,18 @@ def test_cooperative_wait_expiry_is_reported():
     out = st.eval(xq, np.arange(16, dtype=np.int32), np.full(16, models[0], dtype=np.int32))
     ref = oracle_lib.ongpis_predict(3, 0.04, pos, grad, val, sx, sg, xq)
     assert np.array_equal(np.concatenate([out[:, :4], out[:, 4:8]], axis=1).view(np.uint32), ref.view(np.uint32))
+
+
+def test_cluster_the_predictor_cannot_hold_is_refused_at_training():
+    """K4 stages a cluster's row table and points in LDS; a cluster of very many value-only points fits the factorisation
+    but not that staging.  It is refused when it is TRAINED (GPIS_ERR_LIMIT, nothing factorised) instead of making every
+    later test() of the map fail."""
+    import gpismap_amd
+    rng = np.random.default_rng(5)
+    n = 8300                                      # 4 (K + pad) + 16 N bytes > 158 KB with K = N
+    pos = rng.uniform(-0.1, 0.1, (n, 3)).astype(np.float32)
+    P = soa9(3, pos, np.zeros((n, 3), np.float32), np.full(n, -0.2, np.float32), np.full(n, 2e-3, np.float32), np.full(n, 0.05, np.float32))
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    with pytest.raises(gpismap_amd.GpisError) as e:
+        st.train(P, np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    assert "-4" in str(e.value)                   # GPIS_ERR_LIMIT

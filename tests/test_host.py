@@ -203,3 +203,22 @@ def test_flat_tree_matches_oracle_tree(tmp_path):
     r = subprocess.run([exe, "30000"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("identical") == 12 and "MISMATCH" not in r.stdout
+
+
+def test_no_kernel_spills_or_uses_scratch():
+    """the gfx950 code objects of the built library, read through llvm-readelf --notes
+    (tools/kernel_resources.py): no kernel may spill a vector register or carry a private (scratch) segment -- round 2's
+    factorisation kernels spilled 94-134 registers (hoisted 64-bit addresses of the column-major factor, a by-value
+    descriptor copy, volatile LDS accesses through generic pointers), the lookup kernel held 1.5 KB of arrays per lane."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    lib = os.path.join(ROOT, "gpismap_amd", "libgpismap_amd.so")
+    t = kernel_resources.kernel_table(lib)
+    names = kernel_resources.demangle(list(t))
+    assert len(t) >= 30, len(t)
+    assert any("ongpis_train_fused_kernel" in names[k] for k in t) and any("ongpis_eval_kernel" in names[k] for k in t)
+    bad = {names[k]: (r["spill"], r["scratch"]) for k, r in t.items() if r["spill"] or r["scratch"]}   # (SGPRs parked in VGPR lanes are not memory traffic)
+    assert not bad, bad
+    # the dominant kernel keeps its occupancy: K4 at most 128 VGPRs (4 wavefronts per SIMD)
+    assert all(r["vgpr"] <= 128 for k, r in t.items() if "ongpis_eval_kernel" in names[k])
