@@ -311,8 +311,8 @@ def main():
         # HBM bytes per K4 launch: rocprofv3 PMC passes of this command (tools/measure_traffic.sh), valid only for the
         # kernel source they were measured on
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r02_k4_traffic.json")
-        if os.path.exists(tpath):
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_k4_traffic.json" % r) for r in ("r03", "r02")) if os.path.exists(q)), "")
+        if tpath:
             with open(tpath) as fh:
                 tj = json.load(fh)
             if (tj.get("ongpis_test_sha") == file_sha(os.path.join(ROOT, "gpismap_amd", "csrc", "ongpis_test.hip"))

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def gm():
     import gpismap_amd
     g = gpismap_amd.GPisMap3()
-    for f in range(2):
+    for f in range(5):                        # F = 5 frames: the map bench.py measures (BASELINE config 4)
         g.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
     return g
 

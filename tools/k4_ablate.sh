@@ -1,5 +1,5 @@
 #!/bin/bash
-# Builds ablation variants of K4 (ongpis_test.hip with -DK4X=<bits> / -DK4_MINW=<n>) into .ab/libk4_<tag>.so and runs
+# Builds shape variants of K4 (ongpis_test.hip with -DK4_QS / -DK4_MINW / -DK4_NSLOT / ...) into .ab/libk4_<tag>.so and runs
 # tools/k4_bench.py against each (GPISMAP_AMD_LIB selects the library).  Usage: tools/k4_ablate.sh build | run [N...]
 set -e
 cd "$(dirname "$0")/.."

@@ -1,14 +1,15 @@
 #!/bin/bash
 # HBM-side traffic and pipe occupancy of K4 for the bench configuration, collected exactly as MI355X_MICROARCH.md prescribes:
 # separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_* + GRBM_GUI_ACTIVE), each with --kernel-trace only.
-# Writes profiles/r02_k4_pmc.txt (per-kernel sums) and profiles/r02_k4_traffic.json, which bench.py reads as
+# Writes profiles/${ROUND}_k4_pmc.txt (per-kernel sums) and profiles/${ROUND}_k4_traffic.json, which bench.py reads as
 # roofline.traffic ONLY while ongpis_test.hip still has the sha recorded here.
 # Usage (GPU box): tools/measure_traffic.sh          -> results under gpurun_out/, copy into profiles/ afterwards
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
+ROUND=${ROUND:-r03}; export ROUND
 mkdir -p gpurun_out
 CMD="bench.py --steps 1 --warmup 0 --cpu-sample 0 --stress 0 --no-host-api"
-OUT=gpurun_out/r02_k4_pmc.txt
+OUT=gpurun_out/${ROUND}_k4_pmc.txt
 : > $OUT
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
   tag=$(echo $pass | cut -d' ' -f1)
@@ -20,8 +21,8 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY
   python3 profiles/summarize_rocpd.py "$db" | grep -E "eval_kernel" >> $OUT
 done
 python3 - <<'PY'
-import hashlib, json, re
-txt = open("gpurun_out/r02_k4_pmc.txt").read()
+import hashlib, json, os, re
+txt = open("gpurun_out/%s_k4_pmc.txt" % os.environ.get("ROUND", "r03")).read()
 def total(counter):
     s = 0.0
     for line in txt.splitlines():
@@ -39,7 +40,7 @@ sha = hashlib.sha256(open("gpismap_amd/csrc/ongpis_test.hip", "rb").read()).hexd
 json.dump({"ongpis_test_sha": sha, "grid": 256, "frames": 5, "k4_launches": launches, "fetch_kib_raw": fetch_kib, "write_kib_raw": write_kib,
            "hbm_bytes_per_pass": hbm, "hbm_bytes_per_launch": hbm / max(1, launches),
            "note": "FETCH_SIZE x 2 (gfx950 correction for 16-B/lane streams) + WRITE_SIZE (raw); one 256^3 test() pass after 5 synthetic frames"},
-          open("gpurun_out/r02_k4_traffic.json", "w"), indent=1)
-print(open("gpurun_out/r02_k4_traffic.json").read())
+          open("gpurun_out/%s_k4_traffic.json" % os.environ.get("ROUND", "r03"), "w"), indent=1)
+print(open("gpurun_out/%s_k4_traffic.json" % os.environ.get("ROUND", "r03")).read())
 PY
 cat $OUT | cut -c1-160
