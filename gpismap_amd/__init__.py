@@ -97,6 +97,7 @@ def lib():
     L.gpis_ongpis_kernel_matrix.argtypes = [vp, fp, ip, fp, fp, C.c_int, fp]
     L.gpis_ongpis_set_debug.argtypes = [vp, C.c_int, C.c_int]
     L.gpis_ongpis_set_keep_factor.argtypes = [vp, C.c_int]
+    L.gpis_ongpis_set_small_kernel.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
     _lib = L
     return L
@@ -418,6 +419,9 @@ class OnGPIS:
     def set_debug(self, inject=0, wait_limit_ms=0):
         """Bound of the in-kernel waits (0 = default 2 s) and the test-only fault injection of the cooperative kernel."""
         _check(self.L.gpis_ongpis_set_debug(self.h, int(inject), int(wait_limit_ms)), "gpis_ongpis_set_debug")
+
+    def set_small_kernel(self, on=True):
+        _check(self.L.gpis_ongpis_set_small_kernel(self.h, 1 if on else 0), "gpis_ongpis_set_small_kernel")
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

@@ -312,6 +312,11 @@ int gpis_ongpis_set_fused(void* s, int on) {
     ((OnHandle*)s)->st.use_fused = on != 0;
     return GPIS_OK;
 }
+int gpis_ongpis_set_small_kernel(void* s, int on) {
+    if (!s) return GPIS_ERR_ARG;
+    ((OnHandle*)s)->st.use_small_kernel = on != 0;
+    return GPIS_OK;
+}
 int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {
     if (!s || wait_limit_ms < 0 || wait_limit_ms > 20000) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;

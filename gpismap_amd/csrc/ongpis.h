@@ -90,6 +90,8 @@ public:
     int last_train_jobs = 0, last_train_maxK = 0;
     long long last_eval_flops = 0;
     bool profile = false;
+    bool use_small_kernel = false;  // K4 for clusters of at most ONGPIS_SMALL_NBX block rows through the resident-X kernel (opt-in: parity-green,
+                                    // measured SLOWER than the general kernel on MI355X -- 16.1 vs 15.1 ms on the stress configuration)
     bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
     bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
                                  // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
@@ -163,6 +165,7 @@ struct EvalArgs {
     const int* job_q;        // query index per job (sorted by model)
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
+    int use_small;           // classes 0..2 through the resident-X kernel (default) instead of the general one
     int use_table;           // exp table in LDS (else recompute per entry); the launcher clears it when the table does not fit
     int cb;                  // column blocks per B chunk (set by ongpis_eval_launch from the LDS budget)
     int nslot;               // chunks in the LDS ring (2 or 3)
@@ -172,17 +175,21 @@ struct EvalArgs {
 // and 8 above (no upper limit: large clusters run several row groups).  The widest class is cut in three by size
 // (nbx <= 32, <= 48, more) only because the LDS of a launch is sized by its largest cluster: one giant cluster must not
 // push the exp table of every other cluster out of LDS.
-#define ONGPIS_NCLASS 6
+#define ONGPIS_NCLASS 7
+#define ONGPIS_SMALL_NBX 9    // clusters of at most this many block rows (K <= 287) take the resident-X kernel (ongpis_test_small.hip)
 #ifndef K4_QS
 #define K4_QS 1   // measured on the 256^3 bench: 1 set / 128 VGPRs / 2 workgroups per CU 811 ms, 2 sets / 256 VGPRs / 1 per CU 870 ms
 #endif
 #define ONGPIS_TILE_Q (8 * K4_QS)   // queries per K4 workgroup (K4_QS sets of 8 sharing every X tile)
 #define ONGPIS_MAX_K 16384   // allocation sanity bound (10 K^2 bytes per model); the binding limit is K4's LDS: ongpis_eval_fits
 __host__ __device__ inline int ongpis_class_of_nbx(int nbx) {
-    return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= 16 ? 2 : (nbx <= 32 ? 3 : (nbx <= 48 ? 4 : 5))));
+    return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= ONGPIS_SMALL_NBX ? 2 : (nbx <= 16 ? 3 : (nbx <= 32 ? 4 : (nbx <= 48 ? 5 : 6)))));
 }
 int ongpis_eval_class(int nbx);
 bool ongpis_eval_fits(int N, int ld);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
+// classes 0..2 (at most ONGPIS_SMALL_NBX block rows): X resident in registers across consecutive tiles of a cluster
+size_t ongpis_eval_small_lds(int maxN, int maxLd);
+int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 
 }  // namespace gpis

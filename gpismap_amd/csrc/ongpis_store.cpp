@@ -606,7 +606,7 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.use_small = use_small_kernel ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
         rc = ongpis_eval_launch(c, nt, maxN[c], maxLd[c], a, s);
         if (rc) return rc;
     }

@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 }
 
 // Size classes by nbx = ceil((K+1)/32): W wavefronts per workgroup (ongpis.h, ongpis_class_of_nbx).
-static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, K4_W3, K4_W3, K4_W3};
+static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, 4, K4_W3, K4_W3, K4_W3};
 constexpr int kQS = ONGPIS_TILE_Q / 8;
 constexpr int kWavesPerCU = 4 * K4_MINW;   // resident wavefronts per CU the register budget of the kernels admits
 
@@ -378,6 +378,9 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     if (ntiles <= 0) return GPIS_OK;
     if (wclass < 0 || wclass >= ONGPIS_NCLASS) return GPIS_ERR_ARG;
     EvalArgs args = args_in;
+    // clusters of at most ONGPIS_SMALL_NBX block rows: the resident-X kernel (ongpis_test_small.hip), same results bit for bit
+    if (args_in.use_small && wclass <= 2 && maxLd / 32 <= ONGPIS_SMALL_NBX && ongpis_eval_small_lds(maxN, maxLd) <= (size_t)160 * 1024)
+        return ongpis_eval_small_launch(ntiles, maxN, maxLd, args_in, s);
     const int W = kClassW[wclass];
     // LDS budget: the register file admits kWavesPerCU wavefronts per CU, i.e. kWavesPerCU / W workgroups; give each an
     // equal share of the 160 KB and spend what the per-cluster tables leave on the ring of B chunks: NSLOT slots
@@ -411,7 +414,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
          ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW, K4_WP3>},
         {ongpis_eval_kernel<1, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, true, kQS, K4_NBW, 0>,
          ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW, K4_WP3>}};
-    const int kidx = wclass < 3 ? wclass : 3;
+    const int kidx = wclass < 3 ? wclass : (wclass == 3 ? 2 : 3);
     if (ensure_dynamic_lds((const void*)kern[use_table][kidx], 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
 #ifdef GPIS_INSTRUMENT
     k4_trace_arm(args, s);

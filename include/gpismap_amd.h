@@ -151,6 +151,9 @@ int   gpis_ongpis_set_exp_table(void* s, int on);
  * reference matern32_sparse_deriv1_3D / _2D (train), covFnc.cpp:142-256 / :317-402 */
 int   gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out);
 int   gpis_ongpis_set_keep_factor(void* s, int on);
+/* opt-in experiment: prediction for clusters of at most 287 rows through a kernel that keeps the inverse factor in registers
+ * across the queries of a cluster (same results as the general kernel, bit for bit; measured slower on MI355X, default off) */
+int   gpis_ongpis_set_small_kernel(void* s, int on);
 int   gpis_ongpis_set_fused(void* s, int on);
 /* In-kernel waits (the cooperative factorisation of the largest clusters, the pipelined inverse) are bounded: when one
  * expires the batch's models are dropped and training returns GPIS_ERR_STATE.  wait_limit_ms = 0 keeps the default

@@ -26,7 +26,7 @@ def main():
     val = np.concatenate([c[2] for c in cl]); sx = np.concatenate([c[3] for c in cl]); sg = np.concatenate([c[4] for c in cl])
     off = (np.arange(M + 1) * N).astype(np.int32)
     ids = np.arange(M * N, dtype=np.int32)
-    st = gpismap_amd.OnGPIS(dim, scale)
+    st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
     models = st.train(soa9(dim, pos, grad, val, sx, sg), off, ids)
     K = st.model(models[0])["K"]
     xq = (pos[rng.integers(0, M * N, M * Q)] + rng.normal(0, 0.3 * scale, (M * Q, dim))).astype(np.float32)
