@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void scatter_lds_kernel(const int* __restrict_
 }
 
 // single block: exclusive scan of job counts; per-class tile bases.  tot[0..3] = tiles per
-// class (tot[0..5]), tot[6] = total jobs, tot[8..13] = class tile offsets.
+// class (tot[0..6]), tot[15] = total jobs, tot[8..14] = class tile offsets.
 __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restrict__ models, int nmodels,
                                                     const int* __restrict__ cnt, int* __restrict__ base,
                                                     int* __restrict__ tbase, int* __restrict__ cursor,
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(1024) void scan_kernel(const ClusterModel* __restri
             int t = sj[i]; sj[i] = rj; rj += t;
             for (int k = 0; k < ONGPIS_NCLASS; ++k) { int u = st[k][i]; st[k][i] = rt[k]; rt[k] += u; }
         }
-        tot[6] = rj;
+        tot[15] = rj;
         unsigned long long fs = 0;
         for (int i = 0; i < 1024; ++i) fs += sf[i];
         flops[0] = fs;
@@ -518,7 +518,7 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     int tot[20];
     GPIS_HIP(hipMemcpyAsync(tot, d_tot_, sizeof(int) * 20, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
-    last_evals += tot[6];
+    last_evals += tot[15];
     { unsigned long long f; std::memcpy(&f, tot + 16, sizeof(f)); last_flops += (long long)f; }
     for (int c = 0; c < ONGPIS_NCLASS; ++c) if (tot[c] > 0) ++last_launches;
     if (profile) {

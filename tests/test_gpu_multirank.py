@@ -55,3 +55,13 @@ def test_bench_self_launches_from_a_plain_python_call():
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 2 and d["metric"] == "sdf_test_points_per_sec"
+
+
+def test_bench_verify_flag_checks_the_assembled_map_and_reports_phases():
+    """--verify (what tools/scale_check.sh passes on the 8-GPU node, there under nccl): after the timed region the assembled
+    map is compared bit for bit with rank 0's single-rank pass on a 64^3 sub-grid, and per-rank pass / gather / exchange
+    times are reported."""
+    d = _run(2, "sharded", extra=("--verify",))
+    pr = d["per_rank"]
+    assert pr["assembled_equals_single_rank_on_64cubed"] is True
+    assert len(pr["pass_ms"]) == 2 and len(pr["gather_ms"]) == 2 and all(v > 0 for v in pr["exchange_ms_per_frame"])
