@@ -238,31 +238,35 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
         const float a = (float)(sqrt(3.0) / (double)mp->scale);  // covFnc.cpp:147
         const float a2 = a * a;
         for (int r = K + tid; r < 32 * nb; r += kFT) put(r, r, 1.f);   // identity padding of the last block
-        const int P = N * (N + 1) / 2;
-        for (int p = tid; p < P; p += kFT) {
-            int j = (int)((sqrtf(8.f * (float)p + 1.f) - 1.f) * 0.5f);
-            while (j * (j + 1) / 2 > p) --j;
-            while ((j + 1) * (j + 2) / 2 <= p) ++j;
-            const int k = p - j * (j + 1) / 2;     // k <= j
+        // diagonal pairs (k == k): cheap, one thread per point
+        for (int k = tid; k < N; k += kFT) {
             const int kg = gidx[k];
             const int kind[3] = {N + kg, N + kg + ng, N + kg + 2 * ng};
-            if (k == j) {
-                put(k, k, (float)(1.0 + (double)sig[k]));
-                if (kg >= 0) {
-                    const float sg = sig[N + k];
-                    for (int c = 0; c < dim; ++c) {
-                        put(kind[c], k, 0.f);
-                        for (int c2 = 0; c2 < c; ++c2) put(kind[c], kind[c2], 0.f);
-                    }
-                    if (dim == 3) {
-                        for (int c = 0; c < 3; ++c) put(kind[c], kind[c], a2 + sg);
-                    } else {
-                        put(kind[0], kind[0], (float)((double)a2 + sqrt((double)(sig[k] * sg))));  // covFnc.cpp:352
-                        put(kind[1], kind[1], a2 + sg);
-                    }
+            put(k, k, (float)(1.0 + (double)sig[k]));
+            if (kg >= 0) {
+                const float sg = sig[N + k];
+                for (int c = 0; c < dim; ++c) {
+                    put(kind[c], k, 0.f);
+                    for (int c2 = 0; c2 < c; ++c2) put(kind[c], kind[c2], 0.f);
                 }
-                continue;
+                if (dim == 3) {
+                    for (int c = 0; c < 3; ++c) put(kind[c], kind[c], a2 + sg);
+                } else {
+                    put(kind[0], kind[0], (float)((double)a2 + sqrt((double)(sig[k] * sg))));  // covFnc.cpp:352
+                    put(kind[1], kind[1], a2 + sg);
+                }
             }
+        }
+        // off-diagonal pairs k < j (one double-precision exp each): N (N - 1) / 2 of them, dealt evenly -- with the diagonal
+        // pairs in the same list 64 points gave 2080 = 4 x 512 + 32 pairs: a fifth trip for everybody because of 32 lanes
+        const int P = N * (N - 1) / 2;
+        for (int p = tid; p < P; p += kFT) {
+            int j = (int)((sqrtf(8.f * (float)p + 1.f) + 1.f) * 0.5f);      // p = j (j - 1) / 2 + k, k < j
+            while (j * (j - 1) / 2 > p) --j;
+            while ((j + 1) * j / 2 <= p) ++j;
+            const int k = p - j * (j - 1) / 2;
+            const int kg = gidx[k];
+            const int kind[3] = {N + kg, N + kg + ng, N + kg + 2 * ng};
             const float4 xk = x4s[k], xj = x4s[j];
             const int jg = gidx[j];
             const int jind[3] = {N + jg, N + jg + ng, N + jg + 2 * ng};
