@@ -290,11 +290,40 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                         if (b >= c0) {
                             const int cend = min(min(c0 + CB - 1, b), cmax);
 #if K4_AVBUF == 1
+                            if constexpr (TABLE) {
                             float av1[16];
 #pragma unroll 1
                             for (int c = c0; c <= cend; ++c) {
                                 load_a(av1, b, c);
                                 mfma_tile(acc[t][0], acc[t][QS - 1], av1, buf + (size_t)(c - c0) * QS * kTileFloats);
+                            }
+                            } else {
+                            // (clusters too large for the exp table in LDS: generation is heavier there, fewer wavefronts compete for
+                            // the matrix pipe at a time, and a product that waits for its X tile shows -- measured +4.8 % at
+                            // K = 2040 / 2380, -1 % on the table kernels, so only here)
+                            // ONE X-tile buffer used as a ring of four 16-byte pieces: as soon as the four matrix instructions
+                            // that read piece g have been issued, piece g of the NEXT tile of this block row is requested into
+                            // the same registers -- the next product's operands arrive under the current product (3/4 of a
+                            // product = 768 cycles ahead, about one L2 round trip) without a second buffer.  The last tile of
+                            // the row re-requests itself (clamped address: branch-free, harmless).
+                            float av1[16];
+                            load_a(av1, b, c0);
+#pragma unroll 1
+                            for (int c = c0; c <= cend; ++c) {
+                                const float* Bl = buf + (size_t)(c - c0) * QS * kTileFloats + h * kTileStride + l31;
+                                const int cn = min(c + 1, cend);
+                                const int nbase = (b * (b + 1) / 2 + cn) * 4096;
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j)
+                                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[4 * g + j], Bl[(4 * g + j) * 2 * kTileStride], acc[t][0], 0, 0, 0);
+                                    auto q = __builtin_amdgcn_raw_buffer_load_b128(Xrs, Tvoff, nbase + g * 1024, 0);
+                                    av1[4 * g + 0] = __uint_as_float(q[0]); av1[4 * g + 1] = __uint_as_float(q[1]);
+                                    av1[4 * g + 2] = __uint_as_float(q[2]); av1[4 * g + 3] = __uint_as_float(q[3]);
+                                    __builtin_amdgcn_sched_barrier(0);     // keep the request where it is: right behind its four instructions
+                                }
+                            }
                             }
 #else
                             float av[2][16];
