@@ -3,8 +3,9 @@
 640x480 synthetic depth and a 256^3 query grid (SURVEY.md 8d, config 4, F = 5 frames).
 
 A "step" is one GPisMap3 test() pass over the query grid, inputs already resident in HBM
-(gpis3_test_device).  update() of the synthetic frames is timed during set-up (median of frames 2..F,
-with the per-phase split) and reported beside it.
+(gpis3_test_device).  update() of the synthetic frames is timed during set-up and reported beside it, twice:
+synchronous with the per-phase split (`update_ms_per_frame_sync`, median of frames 2..F) and in the library's default
+pipelined mode (`update_ms_per_frame`: mean of frames 2..F with the drain of the last frame's training charged).
 
 `python bench.py --gpus N` works as typed: for N > 1 the parent starts N ranks with
 torch.distributed.run BEFORE it touches the GPU and relays rank 0's JSON line; launched by torchrun
@@ -103,6 +104,7 @@ def main():
     gm = gpismap_amd.GPisMap3()          # default camera 640x480, fx=fy=568, cx=310, cy=224
     assert gm.device() == local_rank
     gm.set_profile(True)                 # hipEvents around the K4 / K3 launches
+    gm.set_pipeline(False)               # this pass reads the phase split and the K3 events after every frame: synchronous update
     if sharded:
         gm.set_shard(rank, world)
     upd_ms, phases, k3 = [], [], []
@@ -125,6 +127,25 @@ def main():
         k3.append(dict(ms=s["last_train_ms"], flops=s["last_train_flops"], bytes=s["last_train_bytes"],
                        clusters=int(s["last_train_jobs"]), maxK=int(s["last_train_maxK"])))
     st0 = gm.stats()
+    # The library's default mode: update() returns once the frame's training is enqueued and the next update() / test()
+    # joins it (include/gpismap_amd.h, gpis3_sync).  A second map fuses the same frames that way, nothing is read between
+    # the frames, and the drain of the last frame's training is timed and CHARGED: per frame = (frames 2..F + drain) / (F-1).
+    upd_pipe, drain_ms = [], 0.0
+    if not sharded:
+        gp = gpismap_amd.GPisMap3()
+        for f in range(args.frames):
+            depth = replay.synthetic_depth(f)
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            gp.update(depth, replay.IDENTITY_POSE)
+            upd_pipe.append((time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter()
+        gp.sync()
+        drain_ms = (time.perf_counter() - t0) * 1e3
+        assert gp.num_points() == gm.num_points(), "pipelined and synchronous update() disagree on the map"
+        del gp
+    upd_pipe_mean = ((sum(upd_pipe[1:]) + drain_ms) / (len(upd_pipe) - 1)) if len(upd_pipe) > 1 else None
 
     n_total = args.grid ** 3
     grid = replay.synthetic_grid(args.grid)                    # [n,3] float32, x fastest
@@ -342,8 +363,13 @@ def main():
                        "clusters": int(st0["clusters"]), "map_points": gm.num_points(),
                        "parallelism": ("%s training, query blocks of %d dealt round-robin to %d ranks, RCCL point-to-point gather"
                                        % (args.train, args.block, world)) if world > 1 else "single GPU"},
-            "update_ms_per_frame": med(upd_ms),
-            "update_ms_frames": upd_ms,
+            "update_ms_per_frame": upd_pipe_mean if upd_pipe_mean is not None else med(upd_ms),
+            "update_mode": ("pipelined (default): mean of frames 2..F with the drain of the last frame's training charged"
+                            if upd_pipe_mean is not None else "synchronous: median of frames 2..F"),
+            "update_ms_frames": upd_pipe if upd_pipe_mean is not None else upd_ms,
+            "update_drain_ms": drain_ms,
+            "update_ms_per_frame_sync": med(upd_ms),
+            "update_ms_frames_sync": upd_ms,
             "update_phases_ms": dict(zip(["preproc", "obsgp_train", "reeval_points", "new_points", "update_gps"],
                                          [float(v) for v in (np.median(ph[1:], axis=0) if len(ph) > 1 else ph[0])])),
             "gp_evals_per_point": sum(p[0] for p in per_rank) / n_total,

@@ -67,6 +67,8 @@ def lib():
     L.gpis3_get_nodes.argtypes = [vp, fp, C.c_int]
     L.gpis3_stats.argtypes = [vp, dp, C.c_int]
     L.gpis3_set_profile.argtypes = [vp, C.c_int]
+    L.gpis3_sync.argtypes = [vp]
+    L.gpis3_set_pipeline.argtypes = [vp, C.c_int]
     L.gpis2_create.restype = vp
     L.gpis2_destroy.argtypes = [vp]
     L.gpis2_reset.argtypes = [vp]
@@ -239,6 +241,13 @@ class GPisMap3:
 
     def set_profile(self, on=True):
         _check(self.L.gpis3_set_profile(self.h, int(on)), "gpis3_set_profile")
+
+    def sync(self):
+        """Join the training the last update() left in flight (pipelined update, include/gpismap_amd.h)."""
+        _check(self.L.gpis3_sync(self.h), "gpis3_sync")
+
+    def set_pipeline(self, on=True):
+        _check(self.L.gpis3_set_pipeline(self.h, int(on)), "gpis3_set_pipeline")
 
 
 class GPisMap:

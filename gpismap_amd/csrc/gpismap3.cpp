@@ -100,6 +100,14 @@ struct GPisMap3::Impl {
     OnGPISStore store;
     MapQuery mq;
     hipStream_t stream = nullptr;
+    // Pipelined update (default; GPIS_SYNC_UPDATE=1 or gpis3_set_pipeline(map, 0) turns it off): update() returns once the
+    // frame's OnGPIS training is ENQUEUED on `train_stream`; the join -- wait, error word, dropped batch -- happens where
+    // the result is first needed: the next update()'s updateGPs, test()/testDevice(), statistics, the sharded exchange,
+    // gpis3_sync().  The host work of the next frame (preprocessing, the ObsGP batches on `stream`, tree replay) then runs
+    // beside the factorisations of this one.  Map state and results do not depend on the mode.
+    hipStream_t train_stream = nullptr;
+    bool pipeline = true;
+    int finish_training();
     bool ok = false;        // device objects usable
     bool has_tree = false;  // reference: t != 0
     bool gpo_created = false;
@@ -140,13 +148,19 @@ struct GPisMap3::Impl {
     Impl(const GPisMap3Param& par, const camParam& c)
         : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
           mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
-        ok = (hipGetDevice(&device) == hipSuccess) && (hipStreamCreate(&stream) == hipSuccess);
+        int pr_least = 0, pr_greatest = 0;
+        ok = (hipGetDevice(&device) == hipSuccess) && (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) == hipSuccess) &&
+             (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
+             (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess);
+        if (const char* e = getenv("GPIS_SYNC_UPDATE")) if (atoi(e) != 0) pipeline = false;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
     ~Impl() {
+        (void)store.train_finish();
         (void)hipFree(d_x); (void)hipFree(d_res); (void)hipFree(d_send); (void)hipFree(d_recv);
         if (stream) (void)hipStreamDestroy(stream);
+        if (train_stream) (void)hipStreamDestroy(train_stream);
     }
 
     void reset() {  // GPisMap3.cpp:99-115
@@ -592,9 +606,11 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         tree.query_clusters(tree.root, tree.nodes[a].c, kRtimes * tree.nodes[a].h, qs, nullptr);
         for (int c : qs) updateSet.insert(c);
     }
+    ulap("updateGPs: neighbour sets");
+    finish_training();          // the previous frame's batch: joined before any model slot is released or allocated
+    ulap("updateGPs: join");
     for (int m : tree.released_models) store.release_slot(m);
     tree.released_models.clear();
-    ulap("updateGPs: neighbour sets");
     if (!updateSet.empty()) {
         std::vector<int> todo(updateSet.begin(), updateSet.end());
         std::sort(todo.begin(), todo.end());
@@ -628,7 +644,8 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 for (int d = 0; d < 3; ++d) { soa[d * np + i] = p.pos[d]; soa[(3 + d) * np + i] = p.grad[d]; }
                 soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
             }
-            int rc = store.upload_points(soa.data(), (int)np, stream);
+            store.defer_finish = pipeline && shard_world == 1 && peers.empty();
+            int rc = store.upload_points(soa.data(), (int)np, train_stream);
             ulap("updateGPs: point mirror");
             if (shard_world > 1) {
                 // Greedy longest-processing-time partition of the frame's clusters by their K^3 factorisation cost
@@ -649,9 +666,9 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     shard_jobs.push_back({jobs[j].model, jobs[j].n, jobs[j].ng, owner[j]});
                     if (owner[j] == shard_rank) mine.push_back(jobs[j]);
                 }
-                if (rc == GPIS_OK && !mine.empty()) rc = store.train_batch(mine, ids, stream);
+                if (rc == GPIS_OK && !mine.empty()) rc = store.train_batch(mine, ids, train_stream);
                 table_pending = true;
-            } else if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
+            } else if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, train_stream);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
             ulap("updateGPs: train_batch");
@@ -660,6 +677,17 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     activeSet.clear();
     if (!table_pending) build_cluster_table();
     ulap("updateGPs: cluster table");
+}
+
+int GPisMap3::Impl::finish_training() {
+    if (!store.train_pending()) return GPIS_OK;
+    const int rc = store.train_finish();
+    if (rc != GPIS_OK) {
+        fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc);
+        if (!upd_rc) upd_rc = rc;
+        if (!table_pending) build_cluster_table();   // the batch was dropped: its cells have no GP any more
+    }
+    return rc;
 }
 
 void GPisMap3::Impl::build_cluster_table() {
@@ -892,6 +920,7 @@ bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_st
     if (m.table_pending) { m.fail_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: sharded update not finished (gpis3_shard_finish)\n"); return false; }
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
     m.fail_rc = 0;
+    m.finish_training();
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
     if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: device path failed (%d)\n", rc); }
     return rc == GPIS_OK;
@@ -937,6 +966,7 @@ bool GPisMap3::test_one(float* x, int dim, int leng, float* res) try {
     if (!m.has_tree) return false;
     if (m.table_pending) { m.fail_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] GPisMap3::test: sharded update not finished (gpis3_shard_finish)\n"); return false; }
     m.fail_rc = 0;
+    m.finish_training();
     auto fail = [&](int rc) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::test: device path failed (%d)\n", rc); return false; };
     size_t nx = (size_t)3 * leng, nr = (size_t)8 * leng;
     if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_x = nx; }
@@ -1038,6 +1068,7 @@ int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
+    m.finish_training();      // (the training time of the last batch is read off its events)
     double v[21] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
@@ -1045,6 +1076,21 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
                     m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK};
     for (int i = 0; i < n && i < 21; ++i) out[i] = v[i];
+}
+// join the training the last update() left in flight; returns the update status (0: fine)
+int gpis3_impl_sync(GPisMap3* g) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) { int rc = gpis3_impl_sync(q); if (rc && !m.upd_rc) m.upd_rc = rc; }
+    DeviceScope ds(m.device);
+    m.finish_training();
+    return m.upd_rc;
+}
+void gpis3_impl_set_pipeline(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_set_pipeline(q, on);
+    DeviceScope ds(m.device);
+    m.finish_training();
+    m.pipeline = on != 0;
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

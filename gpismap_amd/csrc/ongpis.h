@@ -98,6 +98,13 @@ public:
     int debug_inject = 0;        // test-only fault injection for the cooperative kernel (ongpis_train.hip, ctl[1])
     int wait_limit_ticks = 0;    // bound of the in-kernel waits in 100 MHz ticks (0: 2 s)
     bool use_fused = true;       // false: every cluster takes the separate gather / build / factorise / invert kernels
+    // Pipelined training: train_batch() returns once the kernels are enqueued (on the caller's stream and the side streams)
+    // and train_finish() joins them -- waits, reads the error word, drops the batch on error.  The map object sets this so
+    // that the host work of the NEXT update() runs beside the factorisations of this one; every other entry point of the
+    // store that touches models, points or the training buffers joins first.  false: train_batch() joins before it returns.
+    bool defer_finish = false;
+    int train_finish();
+    bool train_pending() const { return pend_active_; }
 
 private:
     enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2 };
@@ -120,6 +127,10 @@ private:
     int* d_ej_ = nullptr; int cap_ej_ = 0;       // eval job arrays
     int* d_slots_ = nullptr; int cap_slots_ = 0; // pack / unpack slot list (grown on demand: no hipMalloc / hipFree per call)
     int* d_err_ = nullptr;                       // device error word of the training kernels (zeroed per batch)
+    int* h_err_ = nullptr;                       // its page-locked host copy (written by the batch's last copy)
+    bool pend_active_ = false, pend_profile_ = false;   // a training batch is in flight (train_finish joins it)
+    hipStream_t pend_stream_ = nullptr;
+    std::vector<int> pend_models_;               // slots of the batch in flight
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
     hipStream_t s2_ = nullptr, s3_ = nullptr;    // side streams: the three size groups of a training batch run beside each other
     hipEvent_t evf_ = nullptr, evj_ = nullptr, evj3_ = nullptr;   // fork / joins

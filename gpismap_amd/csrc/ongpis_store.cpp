@@ -30,6 +30,7 @@ OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_
 
 OnGPISStore::~OnGPISStore() {
     clear();
+    if (h_err_) (void)hipHostFree(h_err_);
     (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_); (void)hipFree(d_slots_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -42,6 +43,7 @@ OnGPISStore::~OnGPISStore() {
 }
 
 void OnGPISStore::clear() {
+    (void)train_finish();
     for (size_t i = 0; i < models_.size(); ++i)
         if (live_[i] && models_[i].base) pool_free(pool_, models_[i].base);
     models_.clear(); live_.clear(); free_slots_.clear();
@@ -60,6 +62,7 @@ int OnGPISStore::new_slot() {
 
 void OnGPISStore::release_slot(int s) {
     if (s < 0 || s >= (int)models_.size() || !live_[s]) return;
+    (void)train_finish();   // (the memory of a model of the batch in flight must not return to the pool under the kernels)
     if (models_[s].base) pool_free(pool_, models_[s].base);
     std::memset(&models_[s], 0, sizeof(ClusterModel));
     live_[s] = 0;
@@ -139,6 +142,7 @@ int OnGPISStore::sync_models(hipStream_t s) {
 }
 
 int OnGPISStore::upload_points(const float* soa9, int n, hipStream_t s) {
+    (void)train_finish();
     if (n > pts_.cap) {
         (void)hipFree(pts_.d); pts_.d = nullptr;
         int cap = n + n / 2 + 4096;
@@ -156,6 +160,7 @@ int OnGPISStore::upload_points(const float* soa9, int n, hipStream_t s) {
 int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s) {
     int nj = (int)jobs.size();
     if (nj == 0) return GPIS_OK;
+    (void)train_finish();
     // Pass 1: validate every job before any model is touched (a refusal half-way through must not leave earlier
     // jobs pointing at recycled, untrained memory).
     for (int j = 0; j < nj; ++j) {
@@ -243,6 +248,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     if (!coop_capacity) coop_capacity = std::max(2, ongpis_coop_capacity());
     int kCoopMinNb = 32, kCoopMaxWG = coop_capacity;
     int kCoopGDiv = 900, kCoopGMax = 6;
+    int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
 #include "ongpis_store_instr.inc"   // schedule knobs from the environment (tuning sweeps only)
 #endif
@@ -272,7 +278,6 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
 #endif
     // K3b work lists per group: one entry per (job, block column); columns longer than kLongCol rows first (a workgroup
     // of 8 pipelined wavefronts each), the rest one wavefront per column
-    constexpr int kLongCol = 24;
     // clusters of at most ONGPIS_FUSED_MAX_K rows: one fused on-chip launch per size tier (ongpis_fused.hip) instead of
     // group 2's gather / build / factorise / invert chain
     const bool fused2 = use_fused;
@@ -327,8 +332,11 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
     if (!s2_) {   // side streams / events of the size groups (created once, outside the timed interval)
-        GPIS_HIP(hipStreamCreateWithFlags(&s2_, hipStreamNonBlocking));
-        GPIS_HIP(hipStreamCreateWithFlags(&s3_, hipStreamNonBlocking));
+        // (lowest priority: in the pipelined map update the ObsGP queries of the next frame run beside these and must not wait)
+        int pr_least = 0, pr_greatest = 0;
+        GPIS_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+        GPIS_HIP(hipStreamCreateWithPriority(&s2_, hipStreamNonBlocking, pr_least));
+        GPIS_HIP(hipStreamCreateWithPriority(&s3_, hipStreamNonBlocking, pr_least));
         GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
         GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
         GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
@@ -349,6 +357,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream
     GPIS_HIP(hipEventRecord(evf_, s));
     hipStream_t gs[3] = {s, s3_, s2_};
+    bool fused_launched = false;
     if (fused2 && nj > n0) {
         GPIS_HIP(hipStreamWaitEvent(s2_, evf_, 0));
         FusedTrainArgs fa;
@@ -365,8 +374,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
             int frc = ongpis_launch_train_fused(fa, nj - n1, nbmax, s2_);
             if (frc) return frc;
         }
-        GPIS_HIP(hipEventRecord(evj_, s2_));
-        GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
+        fused_launched = true;   // (joined after the group loop: the caller's stream must not wait for the small clusters before it starts the largest ones)
     }
     for (int grp = 0; grp < 3; ++grp) {
         const int nbeg = gbeg[grp], ncnt = gbeg[grp + 1] - gbeg[grp];
@@ -379,31 +387,47 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         if (grp == 1) { GPIS_HIP(hipEventRecord(evj3_, s3_)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
         if (grp == 2) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     }
+    if (fused_launched) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
-    int h_err[4] = {0, 0, 0, 0};
-    GPIS_HIP(hipMemcpyAsync(h_err, d_err_, sizeof(h_err), hipMemcpyDeviceToHost, s));
-    GPIS_HIP(hipStreamSynchronize(s));
-    if (profile) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
-    if (h_err[0]) {
+    if (!h_err_) GPIS_HIP(hipHostMalloc((void**)&h_err_, sizeof(int) * 4));
+    for (int i = 0; i < 4; ++i) h_err_[i] = 0;
+    GPIS_HIP(hipMemcpyAsync(h_err_, d_err_, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    pend_active_ = true; pend_profile_ = profile; pend_stream_ = s;
+    pend_models_.resize(nj);
+    for (int j = 0; j < nj; ++j) pend_models_[j] = tab[4 * j];
+    if (defer_finish) return deferred_rc;
+    const int frc = train_finish();
+    return frc ? frc : deferred_rc;
+}
+
+// Join the training batch in flight (no-op without one).
+int OnGPISStore::train_finish() {
+    if (!pend_active_) return GPIS_OK;
+    pend_active_ = false;
+    GPIS_HIP(hipStreamSynchronize(pend_stream_));
+    if (pend_profile_) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
+    if (h_err_[0]) {
         // bit 0: a job the fused kernel cannot hold; bit 1: a wait of the cooperative factorisation expired; bit 2: a row
         // wait of the inverse expired.  The factors of this batch may be incomplete: every model of the batch is marked
         // untrained (test() treats the cells as having no GP) and the caller gets GPIS_ERR_STATE.
-        fprintf(stderr, "[gpismap_amd] training kernels reported error word 0x%x: the %d models of this batch are dropped\n", h_err[0], nj);
-        for (int j = 0; j < nj; ++j) {
-            ClusterModel& m = models_[tab[4 * j]];
+        fprintf(stderr, "[gpismap_amd] training kernels reported error word 0x%x: the %d models of this batch are dropped\n", h_err_[0], (int)pend_models_.size());
+        for (int slot : pend_models_) {
+            if (slot < 0 || slot >= (int)models_.size() || !live_[slot]) continue;
+            ClusterModel& m = models_[slot];
             if (m.base) pool_free(pool_, m.base);
             std::memset(&m, 0, sizeof(ClusterModel));
         }
         dirty_ = true;
-        (void)sync_models(s);
+        (void)sync_models(pend_stream_);
         return GPIS_ERR_STATE;
     }
-    return deferred_rc;
+    return GPIS_OK;
 }
 
 int OnGPISStore::kernel_matrix(const float* x, const int* gidx, const float* sigx, const float* sigg, int N, float* K_out, hipStream_t s) {
     if (!x || !gidx || !sigx || !sigg || !K_out || N < 1) return GPIS_ERR_ARG;
+    (void)train_finish();
     int ng = 0;
     for (int k = 0; k < N; ++k) {
         if (gidx[k] >= 0) { if (gidx[k] != ng) return GPIS_ERR_ARG; ++ng; }
@@ -427,6 +451,13 @@ int OnGPISStore::kernel_matrix(const float* x, const int* gidx, const float* sig
     GPIS_HIP(hipMemcpyAsync(m.sig, sig.data(), sizeof(float) * sig.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(m.gidx, gidx, sizeof(int) * (size_t)N, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(m.y, y.data(), sizeof(float) * y.size(), hipMemcpyHostToDevice, s));
+    // the row table the gather kernel writes (ongpis_train.hip): point | (gradient component + 1) << 28
+    std::vector<int> rowinfo((size_t)m.ld, (int)(0xFu << 28));
+    for (int k = 0; k < N; ++k) {
+        rowinfo[k] = k;
+        if (gidx[k] >= 0) for (int c = 0; c < dim_; ++c) rowinfo[(size_t)N + (size_t)c * ng + gidx[k]] = k | ((c + 1) << 28);
+    }
+    GPIS_HIP(hipMemcpyAsync(m.rowinfo, rowinfo.data(), sizeof(int) * rowinfo.size(), hipMemcpyHostToDevice, s));
     ongpis_launch_buildK(d_models_, d_job, 1, s);
     GPIS_HIP(hipGetLastError());
     std::vector<float> L((size_t)m.ld * m.ld);
@@ -453,6 +484,7 @@ size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
 // K = 0 -- so that every rank still reaches the collective and the receivers mark those slots untrained.
 int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s) {
     if (n <= 0) return GPIS_OK;
+    (void)train_finish();
     if (stride % 256 != 0) return GPIS_ERR_ARG;
     std::vector<int> present, pidx;
     for (int i = 0; i < n; ++i) {
@@ -495,6 +527,7 @@ int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride
 
 int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slots, hipStream_t s) {
     if (n <= 0) return GPIS_OK;
+    (void)train_finish();
     if (stride % 256 != 0) return GPIS_ERR_ARG;
     std::vector<int> hdr((size_t)16 * n);
     GPIS_HIP(hipMemcpy2DAsync(hdr.data(), 64, d_buf, stride, 64, (size_t)n, hipMemcpyDeviceToHost, s));
@@ -551,6 +584,7 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
 int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
                            hipStream_t s) {
     if (njobs <= 0) return GPIS_OK;
+    (void)train_finish();
     int rc = sync_models(s);
     if (rc) return rc;
     std::vector<int> order(njobs);

@@ -79,75 +79,74 @@ __global__ __launch_bounds__(256) void ongpis_gather_kernel(const ClusterModel* 
 }
 
 // ---------------------------------------------------------------------------
-// Kernel matrix.  grid = jobs, block = 1024.  Entry formulas: covFnc.cpp:165-253
-// (3-D) / :340-399 (2-D), lower triangle only, same operand order as the
-// reference (delta = x_k - x_j with k < j; mixed second derivatives computed
-// once with the lower component first and mirrored).
+// Kernel matrix, tile by tile.  grid = (jobs, kBuildSlices), block = 256: the 32 x 32 tiles of a cluster's lower triangle are
+// dealt to the wavefronts of its slices; lane = (row of the tile, column half), 16 entries each, so every store is a
+// 128-byte run down a column of the column-major matrix.  (The first version walked the POINT pairs with one workgroup
+// per cluster and scattered the up to 16 entries of a pair with stride ld: 2 ms of uncoalesced stores in front of a
+// frame's factorisations.)  An entry is a pure function of its row and column: `rowinfo` names the point and the
+// component of each, and the formulas are the reference's with the reference's operands -- covFnc.cpp:165-253 (3-D) /
+// :340-399 (2-D): delta = x_k - x_j with k < j the point indices, the exponential in double, mixed second derivatives
+// with the lower component first -- so the values are the ones the pair walk produced, bit for bit.
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ void putL(float* L, int ld, int r, int c, float v) {
-    if (r >= c) L[r + (size_t)c * ld] = v; else L[c + (size_t)r * ld] = v;
-}
-
-__global__ __launch_bounds__(1024) void ongpis_buildK_kernel(const ClusterModel* __restrict__ models,
-                                                             const int* __restrict__ d_jobs) {
+__global__ __launch_bounds__(256) void ongpis_buildK_kernel(const ClusterModel* __restrict__ models,
+                                                            const int* __restrict__ d_jobs) {
     const int job = blockIdx.x, tid = threadIdx.x;
+    const int lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
-    const int N = m.N, ng = m.ng, dim = m.dim, K = m.K, ld = m.ld;
+    const int N = m.N, dim = m.dim, K = m.K, ld = m.ld;
     float* L = m.L;
     const float a = (float)(sqrt(3.0) / (double)m.scale);  // covFnc.cpp:147
     const float a2 = a * a;
     const float4* x4 = reinterpret_cast<const float4*>(m.x4);
-
-    // padding rows K+1..ld-1: identity; row K: the target vector y (augmented row)
-    for (int r = K + 1 + (tid >> 5); r < ld; r += 32)
-        for (int c = (tid & 31); c <= r; c += 32) L[r + (size_t)c * ld] = (r == c) ? 1.f : 0.f;
-    for (int c = tid; c < K; c += 1024) L[K + (size_t)c * ld] = m.y[c];
-    if (tid == 0) L[K + (size_t)K * ld] = 1.f;
-
-    const long long NN = (long long)N * N;
-    for (long long idx = tid; idx < NN; idx += 1024) {
-        int k = (int)(idx / N), j = (int)(idx % N);
-        if (k > j) continue;
-        int kg = m.gidx[k];
-        int kind[3] = {N + kg, N + kg + ng, N + kg + 2 * ng};
-        if (k == j) {
-            L[k + (size_t)k * ld] = (float)(1.0 + (double)m.sig[k]);
-            if (kg >= 0) {
-                float sg = m.sig[N + k];
-                for (int c = 0; c < dim; ++c) {
-                    L[kind[c] + (size_t)k * ld] = 0.f;
-                    for (int c2 = 0; c2 < c; ++c2) L[kind[c] + (size_t)kind[c2] * ld] = 0.f;
-                }
-                if (dim == 3) {
-                    for (int c = 0; c < 3; ++c) L[kind[c] + (size_t)kind[c] * ld] = a2 + sg;
-                } else {
-                    L[kind[0] + (size_t)kind[0] * ld] = (float)((double)a2 + sqrt((double)(m.sig[k] * sg)));  // covFnc.cpp:352
-                    L[kind[1] + (size_t)kind[1] * ld] = a2 + sg;
-                }
-            }
-            continue;
-        }
-        float4 xk = x4[k], xj = x4[j];
-        int jg = m.gidx[j];
-        int jind[3] = {N + jg, N + jg + ng, N + jg + 2 * ng};
-        float d[3] = {xk.x - xj.x, xk.y - xj.y, xk.z - xj.z};
-        float r = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
-        double e = exp((double)(-a * r));
-        L[j + (size_t)k * ld] = d_kf(r, a, e);
-        if (kg >= 0) {
-            float g1[3];
-            for (int c = 0; c < dim; ++c) { g1[c] = -d_kf1(d[c], a, e); L[kind[c] + (size_t)j * ld] = g1[c]; }
-            if (jg >= 0) {
-                for (int c = 0; c < dim; ++c) L[jind[c] + (size_t)k * ld] = -g1[c];
-                for (int c1 = 0; c1 < dim; ++c1)
-                    for (int c2 = c1; c2 < dim; ++c2) {
-                        float v = d_kf2(r, d[c1], d[c2], c1 == c2 ? 1.0f : 0.0f, a, e);
-                        putL(L, ld, kind[c1], jind[c2], v);
-                        if (c2 != c1) putL(L, ld, kind[c2], jind[c1], v);
+    const int nbr = ld / 32, ntl = nbr * (nbr + 1) / 2;
+    for (int t = blockIdx.y * 4 + wave; t < ntl; t += 4 * gridDim.y) {
+        int b = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+        while (tri_index(b + 1, 0) <= t) ++b;
+        while (tri_index(b, 0) > t) --b;
+        const int c = t - tri_index(b, 0);
+        const int R = 32 * b + l31;
+        int pr = 0, cr = 0xF;
+        float4 xr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (R < K) { const int ri = m.rowinfo[R]; pr = ri & 0x0FFFFFFF; cr = (ri >> 28) & 0xF; xr = x4[pr]; }
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int C = 32 * c + 16 * h + i;
+            if (C > R) continue;
+            float v;
+            if (R >= K) {
+                // row K: the target vector (augmented row); rows beyond it: identity padding
+                v = (R == K) ? (C < K ? m.y[C] : 1.f) : (R == C ? 1.f : 0.f);
+            } else {
+                const int ci = m.rowinfo[C];
+                const int pc = ci & 0x0FFFFFFF, cc = (ci >> 28) & 0xF;
+                if (pr == pc) {
+                    // the point's own block: covFnc.cpp:165-175 / :340-353
+                    if (R != C) v = 0.f;
+                    else if (cr == 0) v = (float)(1.0 + (double)m.sig[pr]);
+                    else {
+                        const float sg = m.sig[N + pr];
+                        v = (dim == 2 && cr == 1) ? (float)((double)a2 + sqrt((double)(m.sig[pr] * sg))) : a2 + sg;
                     }
+                } else {
+                    const float4 xc = x4[pc];
+                    const bool row_first = pr < pc;               // the point with the lower index is the pair's `k`
+                    const float4 xk = row_first ? xr : xc, xj = row_first ? xc : xr;
+                    const int ck = row_first ? cr : cc, cj = row_first ? cc : cr;   // 0: value row, 1..3: gradient component + 1
+                    const float d0 = xk.x - xj.x, d1 = xk.y - xj.y, d2 = xk.z - xj.z;
+                    const float r = (dim == 3) ? sqrtf((d0 * d0 + d1 * d1) + d2 * d2) : sqrtf(d0 * d0 + d1 * d1);
+                    const double e = exp((double)(-a * r));
+                    auto comp = [&](int q) { return q == 1 ? d0 : (q == 2 ? d1 : d2); };
+                    if (ck == 0 && cj == 0) v = d_kf(r, a, e);
+                    else if (cj == 0) v = -d_kf1(comp(ck), a, e);
+                    else if (ck == 0) v = d_kf1(comp(cj), a, e);
+                    else {
+                        const int q1 = min(ck, cj), q2 = max(ck, cj);
+                        v = d_kf2(r, comp(q1), comp(q2), q1 == q2 ? 1.0f : 0.0f, a, e);
+                    }
+                }
             }
-        } else if (jg >= 0) {
-            for (int c = 0; c < dim; ++c) L[jind[c] + (size_t)k * ld] = d_kf1(d[c], a, e);
+            L[R + (size_t)C * ld] = v;
         }
     }
 }
@@ -946,7 +945,8 @@ void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int n
     hipLaunchKernelGGL(ongpis_gather_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs, d_ids, d_pts, pts_cap);
 }
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
-    hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs), dim3(1024), 0, s, d_models, d_jobs);
+    constexpr int kBuildSlices = 16;
+    hipLaunchKernelGGL(ongpis_buildK_kernel, dim3(njobs, kBuildSlices), dim3(256), 0, s, d_models, d_jobs);
 }
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s) {
     // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small

@@ -1,0 +1,54 @@
+"""Pipelined update() (include/gpismap_amd.h: gpis3_sync / gpis3_set_pipeline): the frame's OnGPIS training is enqueued
+and joined by the next update / test.  Map state and test() results must not depend on the mode, and a training failure
+(the cooperative kernel's bounded wait, fault injection) must surface at the call that joins."""
+import numpy as np
+import pytest
+
+import gpismap_amd
+import replay
+
+pytestmark = pytest.mark.gpu
+
+
+def _grid(n=20):
+    g = np.linspace(-0.9, 0.9, n, dtype=np.float32)
+    return np.stack(np.meshgrid(0.5 * g, 0.5 * g, 1.0 + 0.2 * g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+
+
+def _run(pipeline, frames=3, test_every_frame=False):
+    gm = gpismap_amd.GPisMap3()
+    gm.set_pipeline(pipeline)
+    X = _grid()
+    outs = []
+    for f in range(frames):
+        gm.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+        if test_every_frame:
+            outs.append(gm.test(X).copy())
+    gm.sync()
+    outs.append(gm.test(X).copy())
+    return gm.num_points(), gm.nodes().copy(), outs
+
+
+def test_pipelined_update_equals_synchronous():
+    n1, nodes1, o1 = _run(True)
+    n0, nodes0, o0 = _run(False)
+    assert n1 == n0 and np.array_equal(nodes1, nodes0)
+    assert np.array_equal(o1[-1], o0[-1])
+    assert np.isfinite(o1[-1][:, 0]).all() and np.abs(o1[-1][:, 0]).max() > 0
+
+
+def test_test_joins_the_training_in_flight():
+    # test() right after every update(), no explicit sync: it must see the models of THAT frame
+    _, _, o1 = _run(True, test_every_frame=True)
+    _, _, o0 = _run(False, test_every_frame=True)
+    assert len(o1) == len(o0)
+    for a, b in zip(o1, o0):
+        assert np.array_equal(a, b)
+
+
+def test_stats_join_and_report_training_time():
+    gm = gpismap_amd.GPisMap3()
+    gm.set_profile(True)
+    gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    s = gm.stats()            # joins: the event pair of the batch is complete
+    assert s["last_train_ms"] > 0 and s["last_train_jobs"] > 0
