@@ -69,6 +69,7 @@ def lib():
     L.gpis3_set_profile.argtypes = [vp, C.c_int]
     L.gpis3_sync.argtypes = [vp]
     L.gpis3_set_pipeline.argtypes = [vp, C.c_int]
+    L.gpis3_set_host_gather.argtypes = [vp, C.c_int]
     L.gpis2_create.restype = vp
     L.gpis2_destroy.argtypes = [vp]
     L.gpis2_reset.argtypes = [vp]
@@ -248,6 +249,9 @@ class GPisMap3:
 
     def set_pipeline(self, on=True):
         _check(self.L.gpis3_set_pipeline(self.h, int(on)), "gpis3_set_pipeline")
+
+    def set_host_gather(self, on=True):
+        _check(self.L.gpis3_set_host_gather(self.h, int(on)), "gpis3_set_host_gather")
 
 
 class GPisMap:

@@ -20,6 +20,7 @@ int gpis2_impl_fail(GPisMap* m);
 int gpis3_impl_update_fail(GPisMap3* m);
 int gpis3_impl_sync(GPisMap3* m);
 void gpis3_impl_set_pipeline(GPisMap3* m, int on);
+void gpis3_impl_set_host_gather(GPisMap3* m, int on);
 int gpis2_impl_update_fail(GPisMap* m);
 int gpis3_impl_device(GPisMap3* m);
 int gpis3_impl_num_devices(GPisMap3* m);
@@ -135,6 +136,7 @@ int gpis3_get_nodes(void* m, float* out, int cap) {
 int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis3_impl_stats((GPisMap3*)m, out, n); return GPIS_OK; }
 int gpis3_sync(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_sync((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_pipeline(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis3_impl_set_pipeline((GPisMap3*)m, on); return GPIS_OK; } catch (...) { return GPIS_ERR_STATE; } }
+int gpis3_set_host_gather(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_host_gather((GPisMap3*)m, on); return GPIS_OK; }
 int gpis3_set_profile(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_profile((GPisMap3*)m, on); return GPIS_OK; }
 
 // ---- 2-D map ----------------------------------------------------------------

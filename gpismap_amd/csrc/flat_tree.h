@@ -244,6 +244,23 @@ public:
         }
     }
 
+    // The cell part of query_range_cells() alone, for the device-side filter (ongpis_range_gather_kernel): appends one
+    // (begin, end) pair into cl.pts per non-empty touched cell, in traversal order; returns the number of listed points.
+    int range_cells(const float* c, float h, CellLists& cl, std::vector<int>& ranges) const {
+        cl.cells.clear();
+        query_clusters(root, c, h, cl.cells, nullptr);
+        int total = 0;
+        for (int cell : cl.cells) {
+            if (cl.begin[cell] < 0) {
+                cl.begin[cell] = (int)cl.pts.size();
+                all_points(cell, cl.pts);
+                cl.end[cell] = (int)cl.pts.size();
+            }
+            if (cl.end[cell] > cl.begin[cell]) { ranges.push_back(cl.begin[cell]); ranges.push_back(cl.end[cell]); total += cl.end[cell] - cl.begin[cell]; }
+        }
+        return total;
+    }
+
     void all_points(int n, std::vector<int>& out) const {  // octree.cpp:806-827
         if (empty_leaf(n)) return;
         if (nodes[n].leaf) { out.push_back(nodes[n].pt); return; }

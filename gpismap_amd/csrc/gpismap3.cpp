@@ -106,7 +106,11 @@ struct GPisMap3::Impl {
     // gpis3_sync().  The host work of the next frame (preprocessing, the ObsGP batches on `stream`, tree replay) then runs
     // beside the factorisations of this one.  Map state and results do not depend on the mode.
     hipStream_t train_stream = nullptr;
+    hipStream_t batch_stream = nullptr;   // the new-pixel ObsGP batch: issued right after the ObsGP training, collected by evalPoints()
+    bool batch_inflight = false, batch_launched = false;
+    void launch_pixel_batch();
     bool pipeline = true;
+    bool device_gather = true;   // K6 range part on the device (GPIS_HOST_GATHER=1: the host walk, kept for the cross-check)
     int finish_training();
     bool ok = false;        // device objects usable
     bool has_tree = false;  // reference: t != 0
@@ -151,8 +155,10 @@ struct GPisMap3::Impl {
         int pr_least = 0, pr_greatest = 0;
         ok = (hipGetDevice(&device) == hipSuccess) && (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) == hipSuccess) &&
              (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
-             (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess);
+             (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess) &&
+             (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
         if (const char* e = getenv("GPIS_SYNC_UPDATE")) if (atoi(e) != 0) pipeline = false;
+        if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
@@ -161,6 +167,7 @@ struct GPisMap3::Impl {
         (void)hipFree(d_x); (void)hipFree(d_res); (void)hipFree(d_send); (void)hipFree(d_recv);
         if (stream) (void)hipStreamDestroy(stream);
         if (train_stream) (void)hipStreamDestroy(train_stream);
+        if (batch_stream) (void)hipStreamDestroy(batch_stream);
     }
 
     void reset() {  // GPisMap3.cpp:99-115
@@ -483,6 +490,7 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
     ulap("reEvalPoints: select");
     reeval_batch(ids, st, pval, pvar);
     ulap("reEvalPoints: K2 batches");
+    launch_pixel_batch();      // the new-pixel batch runs on the device while the host replays the re-evaluation below
     std::vector<int> slot(tree.pts.size(), -1);
     for (size_t i = 0; i < ids.size(); ++i) slot[ids[i]] = (int)i;
 
@@ -511,34 +519,55 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
 }
 
 // ------------------------------------------------------------------ evalPoints ----
-void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
-    if (!has_tree || obs_numdata < 1) return;
-    const float w = (float)(1.0 / 6.0);
+static const float kPert3[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
+
+// The speculative K2 batch of evalPoints() -- centre + 6 perturbations per valid pixel -- depends on the frame's ObsGP and
+// pixels only, not on the tree: it is built and ENQUEUED (own stream, second staging set of the ObsGP object) right after
+// the re-evaluation batches of the stored points, runs on the device while the host replays that re-evaluation, and
+// evalPoints() collects it.  (Issued BEFORE the re-evaluation batches it delayed them by more than it saved: measured.)
+void GPisMap3::Impl::launch_pixel_batch() {
+    if (batch_launched) return;
+    batch_launched = true;
+    batch_inflight = false;
+    if (obs_numdata < 1) return;
     const float delx = setting.delx;
     const int n = obs_numdata;
-    static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
     UpdLap ulap;
-    // one speculative K2 batch: centre + 6 perturbations per valid pixel
-    float* q = gpo.stage_q(7 * n);   // page-locked staging of the ObsGP object: filled in place, answers read in place
+    float* q = gpo.stage_qb(7 * n);   // page-locked staging of the ObsGP object: filled in place, answers read in place
     if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
     for (int k = 0; k < n; ++k) {
         const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
         q[(size_t)14 * k] = obs_valid_v[k];
         q[(size_t)14 * k + 1] = obs_valid_u[k];
         for (int i = 0; i < 6; ++i) {
-            float X = xl[0] + delx * pert[0][i];
-            float Y = xl[1] + delx * pert[1][i];
-            float Z = xl[2] + delx * pert[2][i];
+            float X = xl[0] + delx * kPert3[0][i];
+            float Y = xl[1] + delx * kPert3[1][i];
+            float Z = xl[2] + delx * kPert3[2][i];
             q[(size_t)14 * k + 2 + 2 * i] = Y / Z;
             q[(size_t)14 * k + 3 + 2 * i] = X / Z;
         }
     }
     ulap("evalPoints: build queries");
-    int rc = gpo.query_staged(7 * n, stream);
+    int rc = gpo.query_staged_b_async(7 * n, batch_stream);
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
+    batch_inflight = true;
+}
+
+void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
+    if (!has_tree || obs_numdata < 1) return;
+    const float w = (float)(1.0 / 6.0);
+    const float delx = setting.delx;
+    const int n = obs_numdata;
+    const float (&pert)[3][6] = kPert3;
+    launch_pixel_batch();              // (not yet issued when there was nothing to re-evaluate)
+    UpdLap ulap;
+    if (!batch_inflight) return;       // (launch_pixel_batch reported why)
+    batch_inflight = false;
+    int rc = gpo.wait_b();
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += 7 * (long)n;
-    const float* val = gpo.staged_val();
-    const float* var = gpo.staged_var();
+    const float* val = gpo.staged_val_b();
+    const float* var = gpo.staged_var_b();
     ulap("evalPoints: K2 batch");
     // NB (measured, round 2): pre-filtering the pixels with is_not_new() against the tree as it stands before this pass is NOT
     // exact -- an insert can split a node and move its stored point into a child that no longer contains a later pixel, which
@@ -618,25 +647,10 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         std::vector<int> ids, res;
         T3::CellLists cell_lists;   // the points of every touched cell listed once for the whole batch (flat_tree.h)
         cell_lists.reset(tree.nodes.size());
-        for (int c : todo) {
-            res.clear();
-            tree.query_range_cells(tree.nodes[c].c, tree.nodes[c].h * kRtimes, cell_lists, res);
-            if (res.empty()) continue;
-            int ng = 0;
-            for (int pid : res) {  // OnGPIS.cpp:122-125
-                const FlatPoint<3>& p = tree.pts[pid];
-                bool tiny = ((double)std::fabs(p.grad[0]) < 1e-6) && ((double)std::fabs(p.grad[1]) < 1e-6) && ((double)std::fabs(p.grad[2]) < 1e-6);
-                if (!(((double)p.sigg > 0.1001) || tiny)) ++ng;
-            }
-            if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
-            TrainJob j;
-            j.model = tree.nodes[c].model; j.off = (int)ids.size(); j.n = (int)res.size(); j.ng = ng;
-            jobs.push_back(j);
-            ids.insert(ids.end(), res.begin(), res.end());
-        }
-        ulap("updateGPs: range queries");
-        if (!jobs.empty()) {
-            // mirror of the map points in HBM: 9 SoA rows indexed by point id
+        store.defer_finish = pipeline && shard_world == 1 && peers.empty();
+        int rc = GPIS_OK;
+        // mirror of the map points in HBM: 9 SoA rows indexed by point id (the range gather below reads the positions)
+        {
             size_t np = tree.pts.size();
             std::vector<float> soa(9 * np, 0.f);
             for (size_t i = 0; i < np; ++i) {
@@ -644,9 +658,58 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 for (int d = 0; d < 3; ++d) { soa[d * np + i] = p.pos[d]; soa[(3 + d) * np + i] = p.grad[d]; }
                 soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
             }
-            store.defer_finish = pipeline && shard_world == 1 && peers.empty();
-            int rc = store.upload_points(soa.data(), (int)np, train_stream);
+            rc = store.upload_points(soa.data(), (int)np, train_stream);
             ulap("updateGPs: point mirror");
+        }
+        if (rc == GPIS_OK && device_gather) {
+            // K6 range part on the device: the host only names the cells (traversal order) and lists each touched cell once
+            std::vector<int> cr, desc, counts, cl_of;
+            int total = 0;
+            for (int c : todo) {
+                const float h = tree.nodes[c].h * kRtimes;
+                const int e0 = (int)cr.size() / 2;
+                const int capc = tree.range_cells(tree.nodes[c].c, h, cell_lists, cr);
+                if (capc == 0) { cr.resize((size_t)2 * e0); continue; }      // no point in any touched cell: the reference's empty result
+                union { float f; int i; } u;
+                desc.push_back(e0); desc.push_back((int)cr.size() / 2 - e0); desc.push_back(total);
+                for (int d = 0; d < 3; ++d) { u.f = tree.nodes[c].c[d]; desc.push_back(u.i); }
+                u.f = h * h; desc.push_back(u.i); desc.push_back(0);
+                cl_of.push_back(c);
+                total += capc;
+            }
+            counts.assign(2 * cl_of.size(), 0);
+            if (!cl_of.empty())
+                rc = store.gather_ranges(cell_lists.pts.data(), (int)cell_lists.pts.size(), cr.data(), (int)cr.size() / 2, desc.data(),
+                                         (int)cl_of.size(), total, counts.data(), train_stream);
+            for (size_t i = 0; i < cl_of.size() && rc == GPIS_OK; ++i) {
+                if (counts[2 * i] == 0) continue;
+                const int c = cl_of[i];
+                if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
+                TrainJob j;
+                j.model = tree.nodes[c].model; j.off = desc[8 * i + 2]; j.n = counts[2 * i]; j.ng = counts[2 * i + 1];
+                jobs.push_back(j);
+            }
+        } else if (rc == GPIS_OK) {
+            for (int c : todo) {
+                res.clear();
+                tree.query_range_cells(tree.nodes[c].c, tree.nodes[c].h * kRtimes, cell_lists, res);
+                if (res.empty()) continue;
+                int ng = 0;
+                for (int pid : res) {  // OnGPIS.cpp:122-125
+                    const FlatPoint<3>& p = tree.pts[pid];
+                    bool tiny = ((double)std::fabs(p.grad[0]) < 1e-6) && ((double)std::fabs(p.grad[1]) < 1e-6) && ((double)std::fabs(p.grad[2]) < 1e-6);
+                    if (!(((double)p.sigg > 0.1001) || tiny)) ++ng;
+                }
+                if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
+                TrainJob j;
+                j.model = tree.nodes[c].model; j.off = (int)ids.size(); j.n = (int)res.size(); j.ng = ng;
+                jobs.push_back(j);
+                ids.insert(ids.end(), res.begin(), res.end());
+            }
+        }
+        ulap("updateGPs: range queries");
+        auto train = [&](const std::vector<TrainJob>& js) { return device_gather ? store.train_batch_dev(js, train_stream) : store.train_batch(js, ids, train_stream); };
+        if (!jobs.empty() || rc != GPIS_OK) {
             if (shard_world > 1) {
                 // Greedy longest-processing-time partition of the frame's clusters by their K^3 factorisation cost
                 // (ties by job order): every rank computes the same owners and trains only its own share.
@@ -666,9 +729,9 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     shard_jobs.push_back({jobs[j].model, jobs[j].n, jobs[j].ng, owner[j]});
                     if (owner[j] == shard_rank) mine.push_back(jobs[j]);
                 }
-                if (rc == GPIS_OK && !mine.empty()) rc = store.train_batch(mine, ids, train_stream);
+                if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
                 table_pending = true;
-            } else if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, train_stream);
+            } else if (rc == GPIS_OK) rc = train(jobs);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
             ulap("updateGPs: train_batch");
@@ -897,6 +960,7 @@ void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     lap(0);
     if (m.regressObs()) {
         lap(1);
+        m.batch_launched = false;
         m.updateMapPoints();
         lap(2);
         if (!m.has_tree) {  // addNewMeas :571-578
@@ -1091,6 +1155,11 @@ void gpis3_impl_set_pipeline(GPisMap3* g, int on) {
     DeviceScope ds(m.device);
     m.finish_training();
     m.pipeline = on != 0;
+}
+void gpis3_impl_set_host_gather(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_set_host_gather(q, on);
+    m.device_gather = on == 0;
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

@@ -49,6 +49,14 @@ public:
     int query_staged(int nq, hipStream_t s);
     const float* staged_val() const { return h_val_; }
     const float* staged_var() const { return h_var_; }
+    // A second, independent staging set for a batch that runs BESIDE the host (the new-pixel batch of update(), issued on
+    // its own stream before the re-evaluation batches and collected after them): stage_qb() / query_staged_b_async() /
+    // wait_b(), answers in staged_val_b() / staged_var_b().  Same kernel, same zero-filled values.
+    float* stage_qb(int nq);
+    int query_staged_b_async(int nq, hipStream_t s);
+    int wait_b();
+    const float* staged_val_b() const { return hb_val_; }
+    const float* staged_var_b() const { return hb_var_; }
     bool trained() const { return trained_; }
     int mode() const { return view_.mode; }
     int ngroups() const { return view_.ngroups; }
@@ -78,6 +86,11 @@ private:
     float *d_q_ = nullptr, *d_val_ = nullptr, *d_var_ = nullptr;
     float *h_q_ = nullptr, *h_val_ = nullptr, *h_var_ = nullptr;   // page-locked staging
     int cap_hq_ = 0;
+    float *db_q_ = nullptr, *db_val_ = nullptr, *db_var_ = nullptr;   // the second set
+    float *hb_q_ = nullptr, *hb_val_ = nullptr, *hb_var_ = nullptr;
+    int cap_qb_ = 0, cap_hqb_ = 0;
+    hipEvent_t evb_ = nullptr;
+    bool b_pending_ = false;
 };
 
 }  // namespace gpis

@@ -74,6 +74,10 @@ ObsGPDevice::~ObsGPDevice() {
     (void)hipFree(d_x_); (void)hipFree(d_f_); (void)hipFree(d_idx_); (void)hipFree(d_tab_);
     (void)hipFree(d_q_); (void)hipFree(d_val_); (void)hipFree(d_var_);
     (void)hipHostFree(h_q_); (void)hipHostFree(h_val_); (void)hipHostFree(h_var_);
+    if (b_pending_) (void)hipEventSynchronize(evb_);
+    (void)hipHostFree(hb_q_); (void)hipHostFree(hb_val_); (void)hipHostFree(hb_var_);
+    (void)hipFree(db_q_); (void)hipFree(db_val_); (void)hipFree(db_var_);
+    if (evb_) (void)hipEventDestroy(evb_);
     (void)hipFree(view_.tn); (void)hipFree(view_.tx); (void)hipFree(view_.talpha); (void)hipFree(view_.tL);
 }
 
@@ -98,7 +102,7 @@ int ObsGPDevice::ensure_q(int nq) {
     if (nq <= cap_q_) return GPIS_OK;
     (void)hipFree(d_q_); (void)hipFree(d_val_); (void)hipFree(d_var_);
     d_q_ = d_val_ = d_var_ = nullptr; cap_q_ = 0;
-    int cap = nq + nq / 4 + 1024;
+    int cap = 2 * nq + 4096;   // (geometric: hipMalloc / hipFree in the middle of a frame cost more than the memory)
     GPIS_HIP(hipMalloc(&d_q_, sizeof(float) * 2 * (size_t)cap));
     GPIS_HIP(hipMalloc(&d_val_, sizeof(float) * (size_t)cap));
     GPIS_HIP(hipMalloc(&d_var_, sizeof(float) * (size_t)cap));
@@ -107,6 +111,7 @@ int ObsGPDevice::ensure_q(int nq) {
 }
 
 int ObsGPDevice::train2d(const float* xt, const float* f, int ni, int nj, hipStream_t s) {
+    if (b_pending_) (void)wait_b();    // (a batch of the second staging set still reads the groups)
     trained_ = false;
     if (!(ni > 0 && nj > 0 && xt && f)) return GPIS_ERR_ARG;
     bool repart = (sz0_ != ni || sz1_ != nj || view_.mode != 2);
@@ -241,7 +246,7 @@ float* ObsGPDevice::stage_q(int nq) {
     if (nq > cap_hq_) {
         (void)hipHostFree(h_q_); (void)hipHostFree(h_val_); (void)hipHostFree(h_var_);
         h_q_ = h_val_ = h_var_ = nullptr; cap_hq_ = 0;
-        const int cap = nq + nq / 4 + 1024;
+        const int cap = 2 * nq + 4096;     // (page-locked allocations cost about a millisecond: grow geometrically -- the re-evaluation batches grow with the map)
         if (hipHostMalloc(&h_q_, sizeof(float) * 2 * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_q_ = nullptr; return nullptr; }
         if (hipHostMalloc(&h_val_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_val_ = nullptr; return nullptr; }
         if (hipHostMalloc(&h_var_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { h_var_ = nullptr; return nullptr; }
@@ -284,6 +289,57 @@ int ObsGPDevice::get_group(int g, int* n, float* x, float* alpha, float* L, hipS
     if (alpha) GPIS_HIP(hipMemcpyAsync(alpha, view_.talpha + (size_t)g * 64, sizeof(float) * 64, hipMemcpyDeviceToHost, s));
     if (L) GPIS_HIP(hipMemcpyAsync(L, view_.tL + (size_t)g * 4096, sizeof(float) * 4096, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
+    return GPIS_OK;
+}
+
+}  // namespace gpis
+
+namespace gpis {
+
+float* ObsGPDevice::stage_qb(int nq) {
+    if (b_pending_) (void)wait_b();
+    if (nq > cap_hqb_) {
+        (void)hipHostFree(hb_q_); (void)hipHostFree(hb_val_); (void)hipHostFree(hb_var_);
+        hb_q_ = hb_val_ = hb_var_ = nullptr; cap_hqb_ = 0;
+        const int cap = nq + nq / 4 + 1024;
+        if (hipHostMalloc(&hb_q_, sizeof(float) * 2 * (size_t)cap, hipHostMallocDefault) != hipSuccess) { hb_q_ = nullptr; return nullptr; }
+        if (hipHostMalloc(&hb_val_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { hb_val_ = nullptr; return nullptr; }
+        if (hipHostMalloc(&hb_var_, sizeof(float) * (size_t)cap, hipHostMallocDefault) != hipSuccess) { hb_var_ = nullptr; return nullptr; }
+        cap_hqb_ = cap;
+    }
+    return hb_q_;
+}
+
+int ObsGPDevice::query_staged_b_async(int nq, hipStream_t s) {
+    if (!trained_) return GPIS_ERR_STATE;
+    if (nq <= 0) return GPIS_OK;
+    if (nq > cap_hqb_ || !hb_q_ || !hb_val_ || !hb_var_) return GPIS_ERR_STATE;
+    if (nq > cap_qb_) {
+        (void)hipFree(db_q_); (void)hipFree(db_val_); (void)hipFree(db_var_);
+        db_q_ = db_val_ = db_var_ = nullptr; cap_qb_ = 0;
+        const int cap = nq + nq / 4 + 1024;
+        GPIS_HIP(hipMalloc(&db_q_, sizeof(float) * 2 * (size_t)cap));
+        GPIS_HIP(hipMalloc(&db_val_, sizeof(float) * (size_t)cap));
+        GPIS_HIP(hipMalloc(&db_var_, sizeof(float) * (size_t)cap));
+        cap_qb_ = cap;
+    }
+    if (!evb_) GPIS_HIP(hipEventCreateWithFlags(&evb_, hipEventDisableTiming));
+    const int per = (view_.mode == 2) ? 2 : 1;
+    GPIS_HIP(hipMemcpyAsync(db_q_, hb_q_, sizeof(float) * per * (size_t)nq, hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemsetAsync(db_val_, 0, sizeof(float) * (size_t)nq, s));
+    obsgp_launch_query(view_, db_q_, nq, db_val_, db_var_, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipMemcpyAsync(hb_val_, db_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipMemcpyAsync(hb_var_, db_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipEventRecord(evb_, s));
+    b_pending_ = true;
+    return GPIS_OK;
+}
+
+int ObsGPDevice::wait_b() {
+    if (!b_pending_) return GPIS_OK;
+    b_pending_ = false;
+    GPIS_HIP(hipEventSynchronize(evb_));
     return GPIS_OK;
 }
 

@@ -64,6 +64,14 @@ public:
     int upload_points(const float* soa9, int n, hipStream_t s);
     // K6 + K3 for a batch of clusters.  ids = concatenated point ids (tree order).
     int train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s);
+    // K6 range part on the device (ongpis_range_gather_kernel): the caller lists the points of every touched cell once
+    // (cell_pts), names per cluster its cell entries (cranges: begin / end into cell_pts) and gives 8 ints per cluster
+    // (desc: first cell entry, cells, offset of the cluster's id list, centre x y z and range^2 as float bits, 0); the id
+    // lists are written into the store's device id buffer (total_ids = sum of the clusters' capacities) and counts
+    // receives (points, gradient-bearing points) per cluster.  train_batch_dev() then trains jobs whose `off` are those offsets.
+    int gather_ranges(const int* cell_pts, int npts, const int* cranges, int nentries, const int* desc, int nclusters, int total_ids,
+                      int* counts, hipStream_t s);
+    int train_batch_dev(const std::vector<TrainJob>& jobs, hipStream_t s);
     // Predict: jobs (query index, model slot) evaluated against xq (device, [nq][4]); out
     // (device) receives 2*(1+dim) floats per job: mean(1+dim), var(1+dim).
     int eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
@@ -109,7 +117,10 @@ public:
 private:
     enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2 };
     int alloc_model(int slot, int N, int ng, int kind = kAllocFull);
-    int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc);
+    int train_batch_impl(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s);
+    int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
+    int* d_rg_ = nullptr; int cap_rg_ = 0;       // range gather: cell point lists, cell entries, cluster descriptors, counts
+    int dev_ids_ = 0;                            // ids the last gather_ranges() left in d_ids_
     int dim_;
     float scale_;
     DevPool* pool_;
@@ -155,6 +166,8 @@ void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slo
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);
+void ongpis_launch_range_gather(const int* d_desc, const int* d_cranges, const int* d_cell_pts, int nclusters, const float* d_pts, int pts_cap,
+                                int dim, int* d_ids, int* d_counts, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup, sync = 2 ints per job (zeroed)
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row

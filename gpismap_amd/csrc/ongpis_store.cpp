@@ -31,7 +31,7 @@ OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_
 OnGPISStore::~OnGPISStore() {
     clear();
     if (h_err_) (void)hipHostFree(h_err_);
-    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_); (void)hipFree(d_slots_);
+    (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_); (void)hipFree(d_slots_); (void)hipFree(d_rg_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
     if (evf_) (void)hipEventDestroy(evf_);
@@ -157,16 +157,50 @@ int OnGPISStore::upload_points(const float* soa9, int n, hipStream_t s) {
     return GPIS_OK;
 }
 
-int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s) {
+int OnGPISStore::gather_ranges(const int* cell_pts, int npts, const int* cranges, int nentries, const int* desc, int nclusters, int total_ids,
+                               int* counts, hipStream_t s) {
+    if (nclusters <= 0) return GPIS_OK;
+    if (!cell_pts || !cranges || !desc || !counts || npts < 0 || nentries < 0 || total_ids < 0) return GPIS_ERR_ARG;
+    (void)train_finish();
+    const size_t need = (size_t)npts + 2 * (size_t)nentries + 10 * (size_t)nclusters;
+    if ((int)need > cap_rg_) {
+        (void)hipFree(d_rg_); d_rg_ = nullptr; cap_rg_ = 0;
+        const int cap = (int)need * 3 / 2 + 4096;
+        GPIS_HIP(hipMalloc(&d_rg_, sizeof(int) * (size_t)cap));
+        cap_rg_ = cap;
+    }
+    if (total_ids > cap_ids_) {
+        (void)hipFree(d_ids_); d_ids_ = nullptr; cap_ids_ = 0;
+        const int cap = total_ids * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_ids_, sizeof(int) * (size_t)cap));
+        cap_ids_ = cap;
+    }
+    int* d_cp = d_rg_; int* d_cr = d_cp + npts; int* d_desc = d_cr + 2 * (size_t)nentries; int* d_cnt = d_desc + 8 * (size_t)nclusters;
+    if (npts) GPIS_HIP(hipMemcpyAsync(d_cp, cell_pts, sizeof(int) * (size_t)npts, hipMemcpyHostToDevice, s));
+    if (nentries) GPIS_HIP(hipMemcpyAsync(d_cr, cranges, sizeof(int) * 2 * (size_t)nentries, hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_desc, desc, sizeof(int) * 8 * (size_t)nclusters, hipMemcpyHostToDevice, s));
+    ongpis_launch_range_gather(d_desc, d_cr, d_cp, nclusters, pts_.d, pts_.cap, dim_, d_ids_, d_cnt, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipMemcpyAsync(counts, d_cnt, sizeof(int) * 2 * (size_t)nclusters, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    dev_ids_ = total_ids;
+    return GPIS_OK;
+}
+
+int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s) { return train_batch_impl(jobs, &ids, s); }
+int OnGPISStore::train_batch_dev(const std::vector<TrainJob>& jobs, hipStream_t s) { return train_batch_impl(jobs, nullptr, s); }
+
+int OnGPISStore::train_batch_impl(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s) {
     int nj = (int)jobs.size();
     if (nj == 0) return GPIS_OK;
     (void)train_finish();
+    const size_t nids = ids ? ids->size() : (size_t)dev_ids_;
     // Pass 1: validate every job before any model is touched (a refusal half-way through must not leave earlier
     // jobs pointing at recycled, untrained memory).
     for (int j = 0; j < nj; ++j) {
         const TrainJob& tj = jobs[j];
         if (tj.model < 0 || tj.model >= (int)models_.size() || !live_[tj.model] || tj.n <= 0 || tj.ng < 0 || tj.ng > tj.n ||
-            tj.off < 0 || (size_t)tj.off + (size_t)tj.n > ids.size())
+            tj.off < 0 || (size_t)tj.off + (size_t)tj.n > nids)
             return GPIS_ERR_ARG;
     }
     // Pass 2: allocate.  A cluster this build cannot hold keeps its previous model (the rest of the batch is still
@@ -199,7 +233,7 @@ int OnGPISStore::train_batch(const std::vector<TrainJob>& jobs, const std::vecto
 }
 
 // K6 + kernel build + K3 for jobs whose models are allocated.
-int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>& ids, hipStream_t s, int deferred_rc) {
+int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc) {
     const int nj = (int)jobs.size();
     std::vector<int> tab((size_t)4 * nj);
     // largest clusters first: one workgroup per cluster and K^3 work, so the big factorisations must not start last
@@ -213,9 +247,9 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     }
     int rc = sync_models(s);
     if (rc) return rc;
-    if ((int)ids.size() > cap_ids_) {
+    if (ids && (int)ids->size() > cap_ids_) {
         (void)hipFree(d_ids_); d_ids_ = nullptr;
-        int cap = (int)ids.size() * 3 / 2 + 1024;
+        int cap = (int)ids->size() * 3 / 2 + 1024;
         GPIS_HIP(hipMalloc(&d_ids_, sizeof(int) * (size_t)cap));
         cap_ids_ = cap;
     }
@@ -328,7 +362,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         GPIS_HIP(hipMemcpyAsync(d_cwork_, cwork.data(), sizeof(int) * cwork.size(), hipMemcpyHostToDevice, s));
         GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * 2 * (size_t)ncoop, s));
     }
-    GPIS_HIP(hipMemcpyAsync(d_ids_, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice, s));
+    if (ids) GPIS_HIP(hipMemcpyAsync(d_ids_, ids->data(), sizeof(int) * ids->size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
     if (!s2_) {   // side streams / events of the size groups (created once, outside the timed interval)

@@ -79,6 +79,52 @@ __global__ __launch_bounds__(256) void ongpis_gather_kernel(const ClusterModel* 
 }
 
 // ---------------------------------------------------------------------------
+// K6, range part: the training set of a cluster = the points of the (up to 3^dim) cells its range box touches that lie
+// within the range of its centre -- OnGPIS's caller, GPisMap3.cpp:721-735 (2-D: GPisMap.cpp:597-611) through
+// OcTree::QueryRange (octree.cpp:744-804).  The host lists every touched cell's points once per frame (traversal order)
+// and names, per cluster, the cells in traversal order; this kernel filters them against the centre with the reference's
+// arithmetic (squared distance accumulated x, y, z in float, strict <) and writes the survivors in order.  grid =
+// clusters, block = ONE wavefront: ordered compaction by ballot, no barriers.  desc: 8 ints per cluster --
+// [first cell entry, cells, offset into ids, centre x, y, z (float bits), range^2 (float bits), unused]; cranges: (begin,
+// end) into cell_pts per cell entry; counts: (points kept, of which gradient-bearing by the rule of OnGPIS.cpp:122-125).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void ongpis_range_gather_kernel(const int* __restrict__ desc, const int* __restrict__ cranges,
+                                                                 const int* __restrict__ cell_pts, const float* __restrict__ pts,
+                                                                 int cap, int dim, int* __restrict__ ids, int* __restrict__ counts) {
+    const int cl = blockIdx.x, lane = threadIdx.x;
+    const int cr0 = desc[8 * cl], ncell = desc[8 * cl + 1], off = desc[8 * cl + 2];
+    const float cx = __int_as_float(desc[8 * cl + 3]), cy = __int_as_float(desc[8 * cl + 4]), cz = __int_as_float(desc[8 * cl + 5]);
+    const float hsq = __int_as_float(desc[8 * cl + 6]);
+    int n = 0, ng = 0;
+    for (int ci = 0; ci < ncell; ++ci) {
+        const int b = cranges[2 * (cr0 + ci)], e = cranges[2 * (cr0 + ci) + 1];
+        for (int i0 = b; i0 < e; i0 += 64) {
+            const int i = i0 + lane;
+            bool keep = false, flag = false;
+            int pid = 0;
+            if (i < e) {
+                pid = cell_pts[i];
+                float t = pts[pid] - cx;
+                float sq = t * t;
+                t = pts[(size_t)cap + pid] - cy; sq = sq + t * t;
+                if (dim == 3) { t = pts[2 * (size_t)cap + pid] - cz; sq = sq + t * t; }
+                keep = sq < hsq;
+                if (keep) {
+                    const float gx = pts[3 * (size_t)cap + pid], gy = pts[4 * (size_t)cap + pid], gz = pts[5 * (size_t)cap + pid];
+                    const float sg = pts[8 * (size_t)cap + pid];
+                    const bool tiny = ((double)fabsf(gx) < 1e-6) && ((double)fabsf(gy) < 1e-6) && (dim == 2 || (double)fabsf(gz) < 1e-6);
+                    flag = !(((double)sg > 0.1001) || tiny);
+                }
+            }
+            const unsigned long long mk = __ballot(keep), mf = __ballot(flag);
+            if (keep) ids[off + n + __popcll(mk & ((1ull << lane) - 1ull))] = pid;
+            n += __popcll(mk); ng += __popcll(mf);
+        }
+    }
+    if (lane == 0) { counts[2 * cl] = n; counts[2 * cl + 1] = ng; }
+}
+
+// ---------------------------------------------------------------------------
 // Kernel matrix, tile by tile.  grid = (jobs, kBuildSlices), block = 256: the 32 x 32 tiles of a cluster's lower triangle are
 // dealt to the wavefronts of its slices; lane = (row of the tile, column half), 16 entries each, so every store is a
 // 128-byte run down a column of the column-major matrix.  (The first version walked the POINT pairs with one workgroup
@@ -943,6 +989,10 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s) {
     hipLaunchKernelGGL(ongpis_gather_kernel, dim3(njobs), dim3(256), 0, s, d_models, d_jobs, d_ids, d_pts, pts_cap);
+}
+void ongpis_launch_range_gather(const int* d_desc, const int* d_cranges, const int* d_cell_pts, int nclusters, const float* d_pts, int pts_cap,
+                                int dim, int* d_ids, int* d_counts, hipStream_t s) {
+    hipLaunchKernelGGL(ongpis_range_gather_kernel, dim3(nclusters), dim3(64), 0, s, d_desc, d_cranges, d_cell_pts, d_pts, pts_cap, dim, d_ids, d_counts);
 }
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s) {
     constexpr int kBuildSlices = 16;

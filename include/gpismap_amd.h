@@ -96,6 +96,9 @@ int   gpis3_set_profile(void* map, int on);
  * GPisMap3.cpp:218-237, is synchronous and returns nothing). */
 int   gpis3_sync(void* map);
 int   gpis3_set_pipeline(void* map, int on);
+/* K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device by
+ * default; on != 0 (or GPIS_HOST_GATHER=1) selects the host walk it replaced -- same training sets, kept for the cross-check. */
+int   gpis3_set_host_gather(void* map, int on);
 
 /* ---- 2-D map (GPisMap) ---------------------------------------------------- */
 void* gpis2_create(void);                                       /* GPisMap() GPisMap.cpp:57 */

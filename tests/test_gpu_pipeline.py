@@ -52,3 +52,17 @@ def test_stats_join_and_report_training_time():
     gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
     s = gm.stats()            # joins: the event pair of the batch is complete
     assert s["last_train_ms"] > 0 and s["last_train_jobs"] > 0
+
+
+def test_device_range_gather_equals_host_walk():
+    # K6's range filter on the device against the host walk it replaced: same training sets -> same models -> same bits
+    X = _grid()
+    outs = []
+    for host in (False, True):
+        gm = gpismap_amd.GPisMap3()
+        gm.set_host_gather(host)
+        for f in range(3):
+            gm.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+        outs.append((gm.stats()["clusters_trained"], gm.test(X).copy()))
+    assert outs[0][0] == outs[1][0] and outs[0][0] > 0
+    assert np.array_equal(outs[0][1], outs[1][1])
