@@ -100,16 +100,17 @@ struct GPisMap3::Impl {
     OnGPISStore store;
     MapQuery mq;
     hipStream_t stream = nullptr;
-    // Pipelined update (default; GPIS_SYNC_UPDATE=1 or gpis3_set_pipeline(map, 0) turns it off): update() returns once the
-    // frame's OnGPIS training is ENQUEUED on `train_stream`; the join -- wait, error word, dropped batch -- happens where
-    // the result is first needed: the next update()'s updateGPs, test()/testDevice(), statistics, the sharded exchange,
-    // gpis3_sync().  The host work of the next frame (preprocessing, the ObsGP batches on `stream`, tree replay) then runs
-    // beside the factorisations of this one.  Map state and results do not depend on the mode.
+    // Pipelined update (opt-in: GPIS_PIPELINE_UPDATE=1 or gpis3_set_pipeline(map, 1); the default is the reference's
+    // synchronous update(), SURVEY 8(b) "Threading"): update() returns once the frame's OnGPIS training is ENQUEUED on
+    // `train_stream`; the join -- wait, error word, dropped batch -- happens where the result is first needed: the next
+    // update()'s updateGPs, test()/testDevice(), statistics, the sharded exchange, gpis3_sync().  The host work of the next
+    // frame (preprocessing, the ObsGP batches on `stream`, tree replay) then runs beside the factorisations of this one.
+    // Map state and results do not depend on the mode.
     hipStream_t train_stream = nullptr;
     hipStream_t batch_stream = nullptr;   // the new-pixel ObsGP batch: issued right after the ObsGP training, collected by evalPoints()
     bool batch_inflight = false, batch_launched = false;
     void launch_pixel_batch();
-    bool pipeline = true;
+    bool pipeline = false;
     bool device_gather = true;   // K6 range part on the device (GPIS_HOST_GATHER=1: the host walk, kept for the cross-check)
     int finish_training();
     bool ok = false;        // device objects usable
@@ -157,7 +158,7 @@ struct GPisMap3::Impl {
              (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
              (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess) &&
              (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
-        if (const char* e = getenv("GPIS_SYNC_UPDATE")) if (atoi(e) != 0) pipeline = false;
+        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) pipeline = atoi(e) != 0;
         if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");

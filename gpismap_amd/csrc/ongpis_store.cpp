@@ -288,13 +288,30 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
 #endif
     int ncoop = 0;
     std::vector<int> cwork;
-    for (int j = 0; j < n0; ++j) {
-        const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
-        if (nbj < kCoopMinNb) break;
-        const int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
-        if ((int)cwork.size() / 3 + G > kCoopMaxWG) break;
-        for (int g = 0; g < G; ++g) { cwork.push_back(j); cwork.push_back(g); cwork.push_back(G); }
-        ncoop = j + 1;
+    {
+        // the G workgroups of a cluster on ONE XCD (they read each other's rows through that XCD's L2): clusters dealt to
+        // the XCD with the fewest workgroups so far, the list interleaved so that entry 8 k + x runs on XCD x
+        // (workgroup ids go round-robin over the XCDs), padded with job = -1 entries whose workgroups exit at once
+        std::vector<int> sub[8];
+        int total = 0;
+        for (int j = 0; j < n0; ++j) {
+            const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+            if (nbj < kCoopMinNb) break;
+            const int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
+            if (total + G > kCoopMaxWG) break;
+            int x = 0;
+            for (int i = 1; i < 8; ++i) if (sub[i].size() < sub[x].size()) x = i;
+            for (int g = 0; g < G; ++g) { sub[x].push_back(j); sub[x].push_back(g); sub[x].push_back(G); }
+            total += G;
+            ncoop = j + 1;
+        }
+        size_t mx = 0;
+        for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 3);
+        for (size_t k = 0; k < mx && total > 0; ++k)
+            for (int x = 0; x < 8; ++x) {
+                if (3 * k < sub[x].size()) { cwork.push_back(sub[x][3 * k]); cwork.push_back(sub[x][3 * k + 1]); cwork.push_back(sub[x][3 * k + 2]); }
+                else { cwork.push_back(-1); cwork.push_back(0); cwork.push_back(1); }
+            }
     }
 #ifdef GPIS_INSTRUMENT
     {   // size profile of the batch: block rows per cluster, by group
@@ -323,22 +340,48 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     int wl_off[3], wl_long[3], wl_mid[3], wl_short[3];
     const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
     const int kRegWaves = ongpis_inverse_short_waves(), kMidWaves = ongpis_inverse_mid_waves();
+    // XCD-aware order of the long and the one-wavefront lists: workgroup ids are dealt round-robin to the 8 XCDs, every XCD
+    // has its own L2, and the block columns of ONE cluster read the same Lt tiles -- so all columns of a cluster go to one
+    // XCD (clusters dealt to the XCDs by accumulated work, the list interleaved so that entry 8 k + x belongs to XCD x,
+    // short lists padded with (-1, 0) entries whose workgroups exit at once).  Measured on the synthetic frames: L2 misses
+    // of the long-column kernel -62 %.
+    auto interleave8 = [](std::vector<int> (&sub)[8], std::vector<int>& out) {
+        size_t mx = 0;
+        for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 2);
+        for (size_t k = 0; k < mx; ++k)
+            for (int x = 0; x < 8; ++x) {
+                if (2 * k < sub[x].size()) { out.push_back(sub[x][2 * k]); out.push_back(sub[x][2 * k + 1]); }
+                else { out.push_back(-1); out.push_back(0); }
+            }
+    };
     for (int grp = 0; grp < 3; ++grp) {
         std::vector<int> wlong, wmid, wshort;
+        std::vector<int> slong[8], smid[8];
+        double wl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int j = gbeg[grp]; j < gbeg[grp + 1]; ++j) {
             const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
             // register path only for clusters whose columns are ALL short (a third launch per group would serialise
             // behind the other two for nothing: the short columns of a large cluster are a few percent of its work)
             const bool reg_cluster = nbj <= kRegCol;
+            std::vector<int> el, em;
+            double cl = 0.0, cm = 0.0;
             for (int c = 0; c < nbj; ++c) {
+                const double cw = (double)(nbj - c) * (nbj - c);
                 if (!reg_cluster) {
-                    if (nbj - c > kLongCol) { wlong.push_back(j); wlong.push_back(c); }
-                    else if ((c - std::max(0, nbj - kLongCol)) % kMidWaves == 0) { wmid.push_back(j); wmid.push_back(c); }   // first of kMidWaves columns
+                    if (nbj - c > kLongCol) { el.push_back(j); el.push_back(c); cl += cw; }
+                    else {
+                        if ((c - std::max(0, nbj - kLongCol)) % kMidWaves == 0) { em.push_back(j); em.push_back(c); }   // first of kMidWaves columns
+                        cm += cw;
+                    }
                 } else if ((c - std::max(0, nbj - kRegCol)) % kRegWaves == 0) {   // one entry per kRegWaves adjacent short columns
                     wshort.push_back(j); wshort.push_back(c);
                 }
             }
+            if (!el.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wl[i] < wl[x]) x = i; slong[x].insert(slong[x].end(), el.begin(), el.end()); wl[x] += cl; }
+            if (!em.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wm[i] < wm[x]) x = i; smid[x].insert(smid[x].end(), em.begin(), em.end()); wm[x] += cm; }
         }
+        interleave8(slong, wlong);
+        interleave8(smid, wmid);
         wl_off[grp] = (int)work.size(); wl_long[grp] = (int)wlong.size() / 2; wl_mid[grp] = (int)wmid.size() / 2;
         wl_short[grp] = (int)wshort.size() / 2;
         work.insert(work.end(), wlong.begin(), wlong.end());

@@ -532,7 +532,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];
     __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
     __shared__ float av[32];
-    const int job = cwork[3 * blockIdx.x], g = cwork[3 * blockIdx.x + 1], G = cwork[3 * blockIdx.x + 2];
+    const int job = cwork[3 * blockIdx.x], g = cwork[3 * blockIdx.x + 1], G = cwork[3 * blockIdx.x + 2];   // (XCD-aware order, job < 0: padding -- ongpis_store.cpp)
+    if (job < 0) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, l31 = lane & 31;
@@ -765,7 +766,8 @@ __global__ __launch_bounds__(64 * (REGZ ? kShortWaves : (NWI == 1 ? kMidWaves : 
     const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float* T = Tall[wave_id];
     const int wave = (NWI == 1) ? 0 : wave_id;                     // position inside the column's team
-    const int job = work[2 * blockIdx.x];
+    const int job = work[2 * blockIdx.x];      // (the host orders the list XCD-aware: ongpis_store.cpp; job < 0: padding)
+    if (job < 0) return;
     const int c = work[2 * blockIdx.x + 1] + (NWI == 1 ? wave_id : 0);
     const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
     const int K = m.K, nb = m.nb, nbx = m.ld / 32;

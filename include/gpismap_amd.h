@@ -89,11 +89,11 @@ int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 va
  * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch */
 int   gpis3_stats(void* map, double* out, int n);
 int   gpis3_set_profile(void* map, int on);
-/* Pipelined update (default on; GPIS_SYNC_UPDATE=1 in the environment or gpis3_set_pipeline(map, 0) turn it off):
- * gpis3_update() returns once the frame's OnGPIS training is enqueued; the next update, test, statistics and the sharded
- * exchange join it first, so results never depend on the mode -- only WHEN a training failure is reported does: by the
- * call that joined.  gpis3_sync() joins explicitly and returns the pending update status (the reference's update(),
- * GPisMap3.cpp:218-237, is synchronous and returns nothing). */
+/* Pipelined update (opt-in: gpis3_set_pipeline(map, 1) or GPIS_PIPELINE_UPDATE=1 in the environment; the default is the
+ * reference's synchronous update(), GPisMap3.cpp:218-237): gpis3_update() returns once the frame's OnGPIS training is
+ * enqueued; the next update, test, statistics and the sharded exchange join it first, so results never depend on the mode --
+ * only WHEN a training failure is reported does: by the call that joined.  gpis3_sync() joins explicitly and returns the
+ * pending update status. */
 int   gpis3_sync(void* map);
 int   gpis3_set_pipeline(void* map, int on);
 /* K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device by
