@@ -169,7 +169,7 @@ void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_range_gather(const int* d_desc, const int* d_cranges, const int* d_cell_pts, int nclusters, const float* d_pts, int pts_cap,
                                 int dim, int* d_ids, int* d_counts, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
-// K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup, sync = 2 ints per job (zeroed)
+// K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup (job < 0: padding), sync = 3 ints per job (zeroed)
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);

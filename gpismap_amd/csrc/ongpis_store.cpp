@@ -395,7 +395,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         cap_work_ = cap;
     }
     if (ncoop > 0) {
-        const size_t need = cwork.size() + 2 * (size_t)ncoop;
+        const size_t need = cwork.size() + 3 * (size_t)ncoop;
         if ((int)need > cap_cwork_) {
             (void)hipFree(d_cwork_); d_cwork_ = nullptr;
             int cap = (int)need * 2 + 1024;
@@ -403,7 +403,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
             cap_cwork_ = cap;
         }
         GPIS_HIP(hipMemcpyAsync(d_cwork_, cwork.data(), sizeof(int) * cwork.size(), hipMemcpyHostToDevice, s));
-        GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * 2 * (size_t)ncoop, s));
+        GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * 3 * (size_t)ncoop, s));
     }
     if (ids) GPIS_HIP(hipMemcpyAsync(d_ids_, ids->data(), sizeof(int) * ids->size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));

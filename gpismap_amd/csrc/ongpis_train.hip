@@ -292,6 +292,12 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
     }
 }
 
+#ifndef K3_T0_NT
+#define K3_T0_NT 3      // tiles per wavefront and round, 8-wavefront tier
+#endif
+#ifndef K3_T0_MINW
+#define K3_T0_MINW 2    // wavefronts per SIMD the 8-wavefront tier is compiled for (2: 256 VGPRs, one workgroup per CU)
+#endif
 #ifndef K3_T1_NT
 #define K3_T1_NT 3      // tiles per wavefront and round, one-wavefront tier (K <= 256)
 #endif
@@ -302,7 +308,7 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
 #define K3_T1_MINW 2    // wavefronts per SIMD the one-wavefront tier is compiled for
 #endif
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : 2) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : K3_T0_MINW) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
                                                               const int* __restrict__ d_jobs) {
     __shared__ __attribute__((aligned(16))) float D[32 * 33];       // diagonal tile, row-major padded (factor workspace)
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];      // factored diagonal tile, column-major (for the solves)
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                                                                 const int* __restrict__ d_jobs, const int* __restrict__ cwork,
                                                                 int* __restrict__ sync, int* __restrict__ ctl) {
     constexpr int NW = 8;
-    __shared__ int abort_s;
+    __shared__ int abort_s[2];     // (two words used alternately: a wait may follow the previous one before every wavefront has read its verdict)
     __shared__ __attribute__((aligned(16))) float D[32 * 33];
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];
     __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
@@ -544,9 +550,10 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     const int ntl = nbr * (nbr + 1) / 2;
     const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
-    int* rowready = sync + 2 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially);
+    int* rowready = sync + 3 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially);
                                          // negative: a workgroup of this cluster gave up (abort)
-    int* alldone = sync + 2 * job + 1;   // workgroups that have finished their rows
+    int* alldone = sync + 3 * job + 1;   // workgroups that have finished their rows
+    int* rowtiles = sync + 3 * job + 2;  // number of leading block rows whose OFF-diagonal tiles are complete (their owner is about to factor the diagonal block)
     const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
     const bool inject = (ctl[1] & 1) != 0;
     const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
@@ -562,6 +569,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
         }
     };
     // one lane polls a device-scope flag, then the workgroup acquires; false: the wait expired or a partner aborted
+    int nwait = 0;
     auto wait_flag = [&](int* f, int v) -> bool {
         if (tid == 0) {
             const long long t0 = wall_clock64();
@@ -578,18 +586,95 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            abort_s = !ok;
+            abort_s[nwait & 1] = !ok;
         }
         __syncthreads();
-        return abort_s == 0;
+        return abort_s[(nwait++) & 1] == 0;
     };
 
+    // The tiles of one block row bi of column j: chain (needs row j's off-diagonal tiles), then -- once L_jj is there -- the
+    // solve, the stores and the incremental diagonal update.
+    auto chain = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
+        if (j > 0) {
+            float a_[2][16], bq[2][16];
+            load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
+#pragma unroll 1
+            for (int p = 0; p < j; p += 2) {
+                if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(bq[1], bi, p + 1); }
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[0][kk], acc, 0, 0, 0);
+                if (p + 1 < j) {
+                    if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(bq[0], bi, p + 2); }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[1][kk], acc, 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto finish = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
+        diag_solve32<true>(acc, Lc, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
+        float* T = Tt[wave];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        float tq[16];      // -L(bi, j) in A-operand order
+        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            float4 q;
+            q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
+            q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
+            q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
+            q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
+            dst[gg * 64 + lane] = q;
+            tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (bi < nb) {     // incremental diagonal of row bi: A(bi,bi) -= L(bi,j) L(bi,j)^T (rows without a pivot have none)
+            f32x16 dacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
+        }
+    };
+    auto publish = [&](int* f, int v) {      // one lane: this workgroup's stores (ordered by the barrier before) become visible, then the counter moves
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (an abort mark of a partner must survive: only move the counter forward from a non-negative value)
+            if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
+                __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+
+    // Look-ahead (round 3).  Two hand-overs per block column: "row j's off-diagonal tiles are final" (rowtiles, published by
+    // row j's owner BEFORE it factors the diagonal block) and "L_jj is there" (rowready).  Everybody accumulates the
+    // product chains of column j -- for up to two owned rows per wavefront, the accumulators wait in registers -- while
+    // the owner's wavefront 0 factorises; only the solves, the stores and the diagonal updates follow the second
+    // hand-over.  (Before: the whole chain of tile (j+1, j) sat between two diagonal factorisations, and the owner's
+    // other seven wavefronts idled through the factorisation.)  Same chains, same order: bit-identical.
     for (int j = 0; j < nb; ++j) {
         const int pw = min(32, K - 32 * j);
-        // ---- row j's owner: factor the accumulated diagonal block, publish the row
-        if (j % G == g) {
+        const bool owner = (j % G == g);
+        const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
+        if (!owner && first >= nbr) continue;                       // nothing left for this workgroup in later columns either
+        const int bi0 = first + wave * G, bi1 = bi0 + NW * G;       // the two look-ahead rows of this wavefront
+        f32x16 acc0, acc1;
+        if (owner) {
             __syncthreads();           // this workgroup's stores of the previous steps (tiles of row j, its diagonal updates)
-            if (wave == 0) {
+            publish(rowtiles, j + 1);
+            if (wave != 0) {
+                if (bi0 < nbr) chain(acc0, bi0, j);
+                if (bi1 < nbr) chain(acc1, bi1, j);
+            } else {
                 // (device-scope loads: the block was modified by other wavefronts of this CU after it was last read here, and
                 // the vector L1 is not refreshed by stores)
                 // (aux 16 = sc1: the device-scope load of the agent-relaxed atomic this replaces -- served by L2, not the CU's L1)
@@ -635,9 +720,12 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                         }
                     }
                 }
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it)
+            }
+            __syncthreads();           // L_jj stored and in Lc; the other wavefronts' chains are accumulated
+            if (!(inject && j == 1)) publish(rowready, j + 1);
+            if (wave == 0) {
+                // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it).  After
+                // the hand-over: nobody in this kernel reads it.
                 f32x16 x;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
@@ -645,77 +733,29 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
+                if (bi0 < nbr) chain(acc0, bi0, j);
+                if (bi1 < nbr) chain(acc1, bi1, j);
             }
-            __syncthreads();
-            if (tid == 0 && !(inject && j == 1)) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                // (an abort mark of a partner must survive: only move the counter forward from a non-negative value)
-                if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
-                    __hip_atomic_store(rowready, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // ---- everybody: acquire row j, then the owned rows below it
-        const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
-        if (first >= nbr) continue;                                   // nothing left for this workgroup in later columns either
-        if (!wait_flag(rowready, j + 1)) return;      // expired / aborted: error word set, the cluster is abandoned
-        if (j % G != g) {     // non-owners rebuild the padded diagonal factor from the published block
+            if (first >= nbr) continue;
+        } else {
+            if (!wait_flag(rowtiles, j + 1)) return;      // expired / aborted: error word set, the cluster is abandoned
+            if (bi0 < nbr) chain(acc0, bi0, j);
+            if (bi1 < nbr) chain(acc1, bi1, j);
+            if (!wait_flag(rowready, j + 1)) return;
+            // non-owners rebuild the padded diagonal factor from the published block
             for (int idx = tid; idx < 1024; idx += 512) {
                 const int c = idx >> 5, r = idx & 31;
                 const float v = L[(size_t)(j * 32 + r) + (size_t)(j * 32 + c) * ld];
                 Lc[c * 32 + r] = (pw == 32 || (r < pw && c < pw)) ? v : (r == c ? 1.f : 0.f);
             }
+            __syncthreads();
         }
-        __syncthreads();
-        for (int bi = first + wave * G; bi < nbr; bi += NW * G) {
+        if (bi0 < nbr) finish(acc0, bi0, j);
+        if (bi1 < nbr) finish(acc1, bi1, j);
+        for (int bi = bi1 + NW * G; bi < nbr; bi += NW * G) {     // (more than two rows per wavefront: the rest without look-ahead)
             f32x16 acc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
-            if (j > 0) {
-                float a_[2][16], bq[2][16];
-                load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
-#pragma unroll 1
-                for (int p = 0; p < j; p += 2) {
-                    if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(bq[1], bi, p + 1); }
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[0][kk], acc, 0, 0, 0);
-                    if (p + 1 < j) {
-                        if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(bq[0], bi, p + 2); }
-#pragma unroll
-                        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[1][kk], acc, 0, 0, 0);
-                    }
-                }
-            }
-            diag_solve32<true>(acc, Lc, h);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
-            float* T = Tt[wave];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            float tq[16];      // -L(bi, j) in A-operand order
-            float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
-#pragma unroll
-            for (int gg = 0; gg < 4; ++gg) {
-                float4 q;
-                q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
-                q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
-                q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
-                q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
-                dst[gg * 64 + lane] = q;
-                tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (bi < nb) {     // incremental diagonal of row bi: A(bi,bi) -= L(bi,j) L(bi,j)^T (rows without a pivot have none)
-                f32x16 dacc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
-            }
+            chain(acc, bi, j);
+            finish(acc, bi, j);
         }
     }
     // ---- all rows done: workgroup 0 runs the back-substitution over the complete factor
@@ -1004,7 +1044,7 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small
     // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
     if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<K3_T1_NT, K3_T1_NW>), dim3(njobs), dim3(64 * K3_T1_NW), 0, s, d_models, d_jobs);
-    else hipLaunchKernelGGL((ongpis_chol_kernel<3, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
+    else hipLaunchKernelGGL((ongpis_chol_kernel<K3_T0_NT, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
 }
 
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
