@@ -102,6 +102,9 @@ def lib():
     L.gpis_ongpis_set_keep_factor.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_small_kernel.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
+    L.gpis_ongpis_set_lazy_inverse.argtypes = [vp, C.c_int]
+    L.gpis3_prepare_test.argtypes = [vp]
+    L.gpis3_set_lazy_inverse.argtypes = [vp, C.c_int]
     _lib = L
     return L
 
@@ -135,7 +138,8 @@ class GPisMap3:
     STAT_KEYS = ("obsgp_groups", "obsgp_queries", "clusters_trained", "late_reevals", "clusters",
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
-                 "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK")
+                 "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK",
+                 "last_inverse_ms", "last_inverse_jobs")
 
     def __init__(self, cam6=None, devices=None):
         """devices: list of HIP device ids for ONE map over several devices (gpis3_create_multi; a device may repeat:
@@ -236,12 +240,19 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 21)()
-        _check(self.L.gpis3_stats(self.h, a, 21), "gpis3_stats")
+        a = (C.c_double * 23)()
+        _check(self.L.gpis3_stats(self.h, a, 23), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def set_profile(self, on=True):
         _check(self.L.gpis3_set_profile(self.h, int(on)), "gpis3_set_profile")
+
+    def prepare_test(self):
+        """Join a pipelined training and compute the inverses the last updates left to the first test()."""
+        _check(self.L.gpis3_prepare_test(self.h), "gpis3_prepare_test")
+
+    def set_lazy_inverse(self, on=True):
+        _check(self.L.gpis3_set_lazy_inverse(self.h, int(on)), "gpis3_set_lazy_inverse")
 
     def sync(self):
         """Join the training the last update() left in flight (pipelined update, include/gpismap_amd.h)."""
@@ -435,6 +446,9 @@ class OnGPIS:
 
     def set_small_kernel(self, on=True):
         _check(self.L.gpis_ongpis_set_small_kernel(self.h, 1 if on else 0), "gpis_ongpis_set_small_kernel")
+
+    def set_lazy_inverse(self, on=True):
+        _check(self.L.gpis_ongpis_set_lazy_inverse(self.h, 1 if on else 0), "gpis_ongpis_set_lazy_inverse")
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

@@ -21,6 +21,8 @@ int gpis3_impl_update_fail(GPisMap3* m);
 int gpis3_impl_sync(GPisMap3* m);
 void gpis3_impl_set_pipeline(GPisMap3* m, int on);
 void gpis3_impl_set_host_gather(GPisMap3* m, int on);
+int gpis3_impl_prepare_test(GPisMap3* m);
+void gpis3_impl_set_lazy_inverse(GPisMap3* m, int on);
 int gpis2_impl_update_fail(GPisMap* m);
 int gpis3_impl_device(GPisMap3* m);
 int gpis3_impl_num_devices(GPisMap3* m);
@@ -137,6 +139,8 @@ int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_A
 int gpis3_sync(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_sync((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_pipeline(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis3_impl_set_pipeline((GPisMap3*)m, on); return GPIS_OK; } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_host_gather(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_host_gather((GPisMap3*)m, on); return GPIS_OK; }
+int gpis3_prepare_test(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_prepare_test((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
+int gpis3_set_lazy_inverse(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_lazy_inverse((GPisMap3*)m, on); return GPIS_OK; }
 int gpis3_set_profile(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_profile((GPisMap3*)m, on); return GPIS_OK; }
 
 // ---- 2-D map ----------------------------------------------------------------
@@ -316,6 +320,11 @@ int gpis_ongpis_set_keep_factor(void* s, int on) {
 int gpis_ongpis_set_fused(void* s, int on) {
     if (!s) return GPIS_ERR_ARG;
     ((OnHandle*)s)->st.use_fused = on != 0;
+    return GPIS_OK;
+}
+int gpis_ongpis_set_lazy_inverse(void* s, int on) {
+    if (!s) return GPIS_ERR_ARG;
+    ((OnHandle*)s)->st.lazy_inverse = on != 0;
     return GPIS_OK;
 }
 int gpis_ongpis_set_small_kernel(void* s, int on) {

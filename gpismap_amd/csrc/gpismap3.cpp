@@ -160,6 +160,7 @@ struct GPisMap3::Impl {
              (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
         if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) pipeline = atoi(e) != 0;
         if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
+        if (const char* e = getenv("GPIS_EAGER_INVERSE")) if (atoi(e) != 0) store.lazy_inverse = false;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
@@ -1134,13 +1135,14 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     m.finish_training();      // (the training time of the last batch is read off its events)
-    double v[21] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[23] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
-                    m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK};
-    for (int i = 0; i < n && i < 21; ++i) out[i] = v[i];
+                    m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK,
+                    (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs};
+    for (int i = 0; i < n && i < 23; ++i) out[i] = v[i];
 }
 // join the training the last update() left in flight; returns the update status (0: fine)
 int gpis3_impl_sync(GPisMap3* g) {
@@ -1156,6 +1158,21 @@ void gpis3_impl_set_pipeline(GPisMap3* g, int on) {
     DeviceScope ds(m.device);
     m.finish_training();
     m.pipeline = on != 0;
+}
+// join the training in flight and compute the inverses it left to the first prediction; returns the update status
+int gpis3_impl_prepare_test(GPisMap3* g) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) { int rc = gpis3_impl_prepare_test(q); if (rc && !m.upd_rc) m.upd_rc = rc; }
+    DeviceScope ds(m.device);
+    m.finish_training();
+    const int rc = m.store.ensure_inverses(m.stream);
+    if (rc && !m.upd_rc) m.upd_rc = rc;
+    return m.upd_rc;
+}
+void gpis3_impl_set_lazy_inverse(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_set_lazy_inverse(q, on);
+    m.store.lazy_inverse = on != 0;
 }
 void gpis3_impl_set_host_gather(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

@@ -581,7 +581,9 @@ int MapQuery::run_chunk(OnGPISStore& store, const float* d_x, int n, float* d_re
 int MapQuery::run(OnGPISStore& store, const float* d_x, int n, float* d_res, hipStream_t s) {
     last_evals = 0; last_eval_ms = 0.f; last_flops = 0; last_launches = 0;
     if (n <= 0) return GPIS_OK;
-    int rc = store.sync_models(s);
+    int rc = store.ensure_inverses(s);     // (lazy inverse: the models retrained since the last prediction get their X now)
+    if (rc) return rc;
+    rc = store.sync_models(s);
     if (rc) return rc;
     // per-class max N (LDS sizing of K4)
     std::fill(h_maxN_.begin(), h_maxN_.end(), 0);

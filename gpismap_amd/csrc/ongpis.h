@@ -111,6 +111,15 @@ public:
     // that the host work of the NEXT update() runs beside the factorisations of this one; every other entry point of the
     // store that touches models, points or the training buffers joins first.  false: train_batch() joins before it returns.
     bool defer_finish = false;
+    // Lazy inverse (default): training of the K > 256 clusters stops at the factor and alpha; the explicit inverse X = L^-1
+    // that prediction multiplies with (K3b) is computed by ensure_inverses() at the FIRST use of the models after a
+    // training -- prediction (eval_jobs, the map's test()), packing for the exchange.  A cluster retrained in several
+    // consecutive updates is inverted once, when somebody asks (the reference's train() does not pay for prediction
+    // either: OnGPIS.cpp:139-143 stops at L and alpha).  false: K3b runs behind K3 in every training batch.
+    bool lazy_inverse = true;
+    int ensure_inverses(hipStream_t s);
+    float last_inverse_ms = 0.f;     // K3b pass of the last ensure_inverses() that had work (profiling on)
+    int last_inverse_jobs = 0;
     int train_finish();
     bool train_pending() const { return pend_active_; }
 
@@ -118,6 +127,11 @@ private:
     enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2 };
     int alloc_model(int slot, int N, int ng, int kind = kAllocFull);
     int train_batch_impl(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s);
+    void build_inverse_work(const std::vector<int>& tab, int jbeg, int jend, int kLongCol, std::vector<int>& work,
+                            int& off, int& nlong, int& nmid, int& nshort) const;
+    void mark_stale(int slot) { if ((int)xstale_.size() < (int)models_.size()) xstale_.resize(models_.size(), 0); xstale_[slot] = 1; stale_list_.push_back(slot); }
+    std::vector<char> xstale_;                   // per slot: the factor is newer than Xt (lazy inverse)
+    std::vector<int> stale_list_;                // slots marked since the last ensure_inverses()
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
     int* d_rg_ = nullptr; int cap_rg_ = 0;       // range gather: cell point lists, cell entries, cluster descriptors, counts
     int dev_ids_ = 0;                            // ids the last gather_ranges() left in d_ids_

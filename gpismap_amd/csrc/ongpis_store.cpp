@@ -47,6 +47,7 @@ void OnGPISStore::clear() {
     for (size_t i = 0; i < models_.size(); ++i)
         if (live_[i] && models_[i].base) pool_free(pool_, models_[i].base);
     models_.clear(); live_.clear(); free_slots_.clear();
+    xstale_.clear(); stale_list_.clear();
     dirty_ = true;
 }
 
@@ -63,6 +64,7 @@ int OnGPISStore::new_slot() {
 void OnGPISStore::release_slot(int s) {
     if (s < 0 || s >= (int)models_.size() || !live_[s]) return;
     (void)train_finish();   // (the memory of a model of the batch in flight must not return to the pool under the kernels)
+    if (s < (int)xstale_.size()) xstale_[s] = 0;
     if (models_[s].base) pool_free(pool_, models_[s].base);
     std::memset(&models_[s], 0, sizeof(ClusterModel));
     live_[s] = 0;
@@ -232,6 +234,128 @@ int OnGPISStore::train_batch_impl(const std::vector<TrainJob>& jobs, const std::
     return train_allocated(ok_jobs, ids, s, deferred_rc);
 }
 
+// K3b work lists for the jobs [jbeg, jend) of a job table (4 ints per job: model, offset, N, ng): one entry per (job, block
+// column); columns longer than kLongCol rows first (a workgroup of 8 pipelined wavefronts each), then the first of every
+// kMidWaves adjacent one-wavefront columns, then the short columns of the clusters whose columns are all short.
+// XCD-aware order of the long and the one-wavefront lists: workgroup ids are dealt round-robin to the 8 XCDs, every XCD
+// has its own L2, and the block columns of ONE cluster read the same Lt tiles -- so all columns of a cluster go to one
+// XCD (clusters dealt to the XCDs by accumulated work, the list interleaved so that entry 8 k + x belongs to XCD x,
+// short lists padded with (-1, 0) entries whose workgroups exit at once).  Measured on the synthetic frames: L2 misses
+// of the long-column kernel -62 %.
+void OnGPISStore::build_inverse_work(const std::vector<int>& tab, int jbeg, int jend, int kLongCol, std::vector<int>& work,
+                                     int& off, int& nlong, int& nmid, int& nshort) const {
+    const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
+    const int kRegWaves = ongpis_inverse_short_waves(), kMidWaves = ongpis_inverse_mid_waves();
+    auto interleave8 = [](std::vector<int> (&sub)[8], std::vector<int>& out) {
+        size_t mx = 0;
+        for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 2);
+        for (size_t k = 0; k < mx; ++k)
+            for (int x = 0; x < 8; ++x) {
+                if (2 * k < sub[x].size()) { out.push_back(sub[x][2 * k]); out.push_back(sub[x][2 * k + 1]); }
+                else { out.push_back(-1); out.push_back(0); }
+            }
+    };
+    std::vector<int> wlong, wmid, wshort;
+    std::vector<int> slong[8], smid[8];
+    double wl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int j = jbeg; j < jend; ++j) {
+        const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+        // register path only for clusters whose columns are ALL short (a third launch per group would serialise
+        // behind the other two for nothing: the short columns of a large cluster are a few percent of its work)
+        const bool reg_cluster = nbj <= kRegCol;
+        std::vector<int> el, em;
+        double cl = 0.0, cm = 0.0;
+        for (int c = 0; c < nbj; ++c) {
+            const double cw = (double)(nbj - c) * (nbj - c);
+            if (!reg_cluster) {
+                if (nbj - c > kLongCol) { el.push_back(j); el.push_back(c); cl += cw; }
+                else {
+                    if ((c - std::max(0, nbj - kLongCol)) % kMidWaves == 0) { em.push_back(j); em.push_back(c); }   // first of kMidWaves columns
+                    cm += cw;
+                }
+            } else if ((c - std::max(0, nbj - kRegCol)) % kRegWaves == 0) {   // one entry per kRegWaves adjacent short columns
+                wshort.push_back(j); wshort.push_back(c);
+            }
+        }
+        if (!el.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wl[i] < wl[x]) x = i; slong[x].insert(slong[x].end(), el.begin(), el.end()); wl[x] += cl; }
+        if (!em.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wm[i] < wm[x]) x = i; smid[x].insert(smid[x].end(), em.begin(), em.end()); wm[x] += cm; }
+    }
+    interleave8(slong, wlong);
+    interleave8(smid, wmid);
+    off = (int)work.size(); nlong = (int)wlong.size() / 2; nmid = (int)wmid.size() / 2; nshort = (int)wshort.size() / 2;
+    work.insert(work.end(), wlong.begin(), wlong.end());
+    work.insert(work.end(), wmid.begin(), wmid.end());
+    work.insert(work.end(), wshort.begin(), wshort.end());
+}
+
+// The explicit inverses (K3b) of every model whose factor is newer than its X: with lazy_inverse, training leaves them to
+// the first use of the models -- prediction, packing -- so that a cluster retrained in several consecutive updates is
+// inverted ONCE, when somebody asks.  No-op when nothing is stale.
+int OnGPISStore::ensure_inverses(hipStream_t s) {
+    int frc = train_finish();
+    if (frc) return frc;
+    if (stale_list_.empty()) return GPIS_OK;
+    std::vector<int> slots;
+    for (int slot : stale_list_) {
+        if (slot < 0 || slot >= (int)xstale_.size() || slot >= (int)models_.size() || !xstale_[slot]) continue;   // (released, or listed twice)
+        xstale_[slot] = 0;
+        if (live_[slot] && models_[slot].base && models_[slot].Zt) slots.push_back(slot);    // (retrained on chip since: its X is there)
+    }
+    stale_list_.clear();
+    const int nj = (int)slots.size();
+    if (nj == 0) return GPIS_OK;
+    std::stable_sort(slots.begin(), slots.end(), [&](int a, int b) { return models_[a].K > models_[b].K; });   // largest first
+    std::vector<int> tab((size_t)4 * nj);
+    for (int j = 0; j < nj; ++j) { const ClusterModel& m = models_[slots[j]]; tab[4 * j] = slots[j]; tab[4 * j + 1] = 0; tab[4 * j + 2] = m.N; tab[4 * j + 3] = m.ng; }
+    int rc = sync_models(s);
+    if (rc) return rc;
+    std::vector<int> work;
+    int off = 0, nlong = 0, nmid = 0, nshort = 0;
+    build_inverse_work(tab, 0, nj, 24, work, off, nlong, nmid, nshort);
+    if (4 * nj > cap_jobs_) {
+        (void)hipFree(d_jobs_); d_jobs_ = nullptr;
+        int cap = 4 * nj * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_jobs_, sizeof(int) * (size_t)cap));
+        cap_jobs_ = cap;
+    }
+    if ((int)work.size() > cap_work_) {
+        (void)hipFree(d_work_); d_work_ = nullptr;
+        int cap = (int)work.size() * 3 / 2 + 1024;
+        GPIS_HIP(hipMalloc(&d_work_, sizeof(int) * (size_t)cap));
+        cap_work_ = cap;
+    }
+    if (!d_err_) GPIS_HIP(hipMalloc(&d_err_, sizeof(int) * 4));
+    if (!h_err_) GPIS_HIP(hipHostMalloc((void**)&h_err_, sizeof(int) * 4));
+    const int ctl[4] = {0, 0, wait_limit_ticks, 0};
+    GPIS_HIP(hipMemcpyAsync(d_err_, ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
+    GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
+    if (profile) {
+        if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
+        GPIS_HIP(hipEventRecord(ev0_, s));
+    }
+    ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off, nlong, nmid, nshort, d_err_, s);
+    GPIS_HIP(hipGetLastError());
+    if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
+    for (int i = 0; i < 4; ++i) h_err_[i] = 0;
+    GPIS_HIP(hipMemcpyAsync(h_err_, d_err_, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipStreamSynchronize(s));
+    if (profile) GPIS_HIP(hipEventElapsedTime(&last_inverse_ms, ev0_, ev1_));
+    last_inverse_jobs = nj;
+    if (h_err_[0]) {
+        fprintf(stderr, "[gpismap_amd] inverse kernels reported error word 0x%x: the %d models of this pass are dropped\n", h_err_[0], nj);
+        for (int slot : slots) {
+            ClusterModel& m = models_[slot];
+            if (m.base) pool_free(pool_, m.base);
+            std::memset(&m, 0, sizeof(ClusterModel));
+        }
+        dirty_ = true;
+        (void)sync_models(s);
+        return GPIS_ERR_STATE;
+    }
+    return GPIS_OK;
+}
+
 // K6 + kernel build + K3 for jobs whose models are allocated.
 int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc) {
     const int nj = (int)jobs.size();
@@ -337,57 +461,10 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     while (fused2 && n1 < nj && (tab[4 * n1 + 2] + dim_ * tab[4 * n1 + 3] + 31) / 32 > 5) ++n1;
     const int gbeg[4] = {0, ncoop, n0, nsep};
     std::vector<int> work;
-    int wl_off[3], wl_long[3], wl_mid[3], wl_short[3];
-    const int kRegCol = ongpis_inverse_short_rows();   // columns this short keep their transposed tiles in registers
-    const int kRegWaves = ongpis_inverse_short_waves(), kMidWaves = ongpis_inverse_mid_waves();
-    // XCD-aware order of the long and the one-wavefront lists: workgroup ids are dealt round-robin to the 8 XCDs, every XCD
-    // has its own L2, and the block columns of ONE cluster read the same Lt tiles -- so all columns of a cluster go to one
-    // XCD (clusters dealt to the XCDs by accumulated work, the list interleaved so that entry 8 k + x belongs to XCD x,
-    // short lists padded with (-1, 0) entries whose workgroups exit at once).  Measured on the synthetic frames: L2 misses
-    // of the long-column kernel -62 %.
-    auto interleave8 = [](std::vector<int> (&sub)[8], std::vector<int>& out) {
-        size_t mx = 0;
-        for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 2);
-        for (size_t k = 0; k < mx; ++k)
-            for (int x = 0; x < 8; ++x) {
-                if (2 * k < sub[x].size()) { out.push_back(sub[x][2 * k]); out.push_back(sub[x][2 * k + 1]); }
-                else { out.push_back(-1); out.push_back(0); }
-            }
-    };
-    for (int grp = 0; grp < 3; ++grp) {
-        std::vector<int> wlong, wmid, wshort;
-        std::vector<int> slong[8], smid[8];
-        double wl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int j = gbeg[grp]; j < gbeg[grp + 1]; ++j) {
-            const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
-            // register path only for clusters whose columns are ALL short (a third launch per group would serialise
-            // behind the other two for nothing: the short columns of a large cluster are a few percent of its work)
-            const bool reg_cluster = nbj <= kRegCol;
-            std::vector<int> el, em;
-            double cl = 0.0, cm = 0.0;
-            for (int c = 0; c < nbj; ++c) {
-                const double cw = (double)(nbj - c) * (nbj - c);
-                if (!reg_cluster) {
-                    if (nbj - c > kLongCol) { el.push_back(j); el.push_back(c); cl += cw; }
-                    else {
-                        if ((c - std::max(0, nbj - kLongCol)) % kMidWaves == 0) { em.push_back(j); em.push_back(c); }   // first of kMidWaves columns
-                        cm += cw;
-                    }
-                } else if ((c - std::max(0, nbj - kRegCol)) % kRegWaves == 0) {   // one entry per kRegWaves adjacent short columns
-                    wshort.push_back(j); wshort.push_back(c);
-                }
-            }
-            if (!el.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wl[i] < wl[x]) x = i; slong[x].insert(slong[x].end(), el.begin(), el.end()); wl[x] += cl; }
-            if (!em.empty()) { int x = 0; for (int i = 1; i < 8; ++i) if (wm[i] < wm[x]) x = i; smid[x].insert(smid[x].end(), em.begin(), em.end()); wm[x] += cm; }
-        }
-        interleave8(slong, wlong);
-        interleave8(smid, wmid);
-        wl_off[grp] = (int)work.size(); wl_long[grp] = (int)wlong.size() / 2; wl_mid[grp] = (int)wmid.size() / 2;
-        wl_short[grp] = (int)wshort.size() / 2;
-        work.insert(work.end(), wlong.begin(), wlong.end());
-        work.insert(work.end(), wmid.begin(), wmid.end());
-        work.insert(work.end(), wshort.begin(), wshort.end());
-    }
+    int wl_off[3] = {0, 0, 0}, wl_long[3] = {0, 0, 0}, wl_mid[3] = {0, 0, 0}, wl_short[3] = {0, 0, 0};
+    const bool lazy = lazy_inverse;     // K3b deferred to the first use of the models (ensure_inverses)
+    if (!lazy)
+        for (int grp = 0; grp < 3; ++grp) build_inverse_work(tab, gbeg[grp], gbeg[grp + 1], kLongCol, work, wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp]);
     if ((int)work.size() > cap_work_) {
         (void)hipFree(d_work_); d_work_ = nullptr;
         int cap = (int)work.size() * 3 / 2 + 1024;
@@ -407,7 +484,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     }
     if (ids) GPIS_HIP(hipMemcpyAsync(d_ids_, ids->data(), sizeof(int) * ids->size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
-    GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
+    if (!work.empty()) GPIS_HIP(hipMemcpyAsync(d_work_, work.data(), sizeof(int) * work.size(), hipMemcpyHostToDevice, s));
+    if (lazy) for (int j = 0; j < nsep; ++j) mark_stale(tab[4 * j]);
     if (!s2_) {   // side streams / events of the size groups (created once, outside the timed interval)
         // (lowest priority: in the pipelined map update the ObsGP queries of the next frame run beside these and must not wait)
         int pr_least = 0, pr_greatest = 0;
@@ -460,7 +538,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
-        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], d_err_, gs[grp]);
+        if (!lazy) ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], d_err_, gs[grp]);
         if (grp == 1) { GPIS_HIP(hipEventRecord(evj3_, s3_)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
         if (grp == 2) { GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0)); }
     }
@@ -561,7 +639,7 @@ size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
 // K = 0 -- so that every rank still reaches the collective and the receivers mark those slots untrained.
 int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s) {
     if (n <= 0) return GPIS_OK;
-    (void)train_finish();
+    { const int erc = ensure_inverses(s); if (erc) return erc; }
     if (stride % 256 != 0) return GPIS_ERR_ARG;
     std::vector<int> present, pidx;
     for (int i = 0; i < n; ++i) {
@@ -628,6 +706,7 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
             dirty_ = true;
             continue;
         }
+        if (slots[i] < (int)xstale_.size()) xstale_[slots[i]] = 0;     // (an imported model carries its X)
         int rc = alloc_model(slots[i], N, ng, kAllocPredictOnly);
         if (rc) return bail(rc);
         present.push_back(slots[i]); pidx.push_back(i);
@@ -661,8 +740,9 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
 int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_job_model, int njobs, float* d_out,
                            hipStream_t s) {
     if (njobs <= 0) return GPIS_OK;
-    (void)train_finish();
-    int rc = sync_models(s);
+    int rc = ensure_inverses(s);
+    if (rc) return rc;
+    rc = sync_models(s);
     if (rc) return rc;
     std::vector<int> order(njobs);
     std::iota(order.begin(), order.end(), 0);

@@ -83,10 +83,11 @@ int   gpis3_shard_finish(void* map);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
-/* out[0..20]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
+/* out[0..22]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
  * GP evaluations of last test, ms in K4 of last test (profiling on), device bytes, algorithmic flops of last test, K4 launches,
  * ms in K6+K3+K3b of last update (profiling on), model bytes, update phases ms [preproc, ObsGP train, re-evaluation,
- * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch */
+ * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch, ms and clusters of the
+ * last deferred inverse pass (profiling on) */
 int   gpis3_stats(void* map, double* out, int n);
 int   gpis3_set_profile(void* map, int on);
 /* Pipelined update (opt-in: gpis3_set_pipeline(map, 1) or GPIS_PIPELINE_UPDATE=1 in the environment; the default is the
@@ -99,6 +100,13 @@ int   gpis3_set_pipeline(void* map, int on);
 /* K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device by
  * default; on != 0 (or GPIS_HOST_GATHER=1) selects the host walk it replaced -- same training sets, kept for the cross-check. */
 int   gpis3_set_host_gather(void* map, int on);
+/* Lazy inverse at map level (default on; GPIS_EAGER_INVERSE=1 or gpis3_set_lazy_inverse(map, 0) turn it off): update() trains
+ * factors and alpha; the explicit inverses are computed by the first test() after it (or by gpis3_prepare_test(), which also
+ * joins a pipelined training) -- once per cluster, however many updates retrained it in between.  With a test() after
+ * every update() the total work is unchanged; with several updates per test() the inverses of the intermediate factors
+ * are never computed.  Results do not depend on the mode. */
+int   gpis3_prepare_test(void* map);
+int   gpis3_set_lazy_inverse(void* map, int on);
 
 /* ---- 2-D map (GPisMap) ---------------------------------------------------- */
 void* gpis2_create(void);                                       /* GPisMap() GPisMap.cpp:57 */
@@ -165,6 +173,11 @@ int   gpis_ongpis_set_keep_factor(void* s, int on);
  * across the queries of a cluster (same results as the general kernel, bit for bit; measured slower on MI355X, default off) */
 int   gpis_ongpis_set_small_kernel(void* s, int on);
 int   gpis_ongpis_set_fused(void* s, int on);
+/* Lazy inverse (default on): training of clusters of more than 256 rows stops at the factor and alpha (what
+ * OnGPIS::train computes, OnGPIS.cpp:139-143); the explicit inverse the prediction kernel multiplies with is computed at the
+ * first prediction / packing after a training, once per cluster however often it was retrained in between.  on = 0: the
+ * inverse runs behind the factorisation in every training batch. */
+int   gpis_ongpis_set_lazy_inverse(void* s, int on);
 /* In-kernel waits (the cooperative factorisation of the largest clusters, the pipelined inverse) are bounded: when one
  * expires the batch's models are dropped and training returns GPIS_ERR_STATE.  wait_limit_ms = 0 keeps the default
  * (2 s); inject != 0 is a TEST hook that makes one workgroup of every cooperative cluster withhold a hand-over, so that

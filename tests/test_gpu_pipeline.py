@@ -66,3 +66,26 @@ def test_device_range_gather_equals_host_walk():
         outs.append((gm.stats()["clusters_trained"], gm.test(X).copy()))
     assert outs[0][0] == outs[1][0] and outs[0][0] > 0
     assert np.array_equal(outs[0][1], outs[1][1])
+
+
+def test_lazy_inverse_equals_eager():
+    # default: update() trains factors and alpha, the first test() computes the explicit inverses.  Eager mode (the inverse
+    # behind every factorisation) must answer with the same bits, also when a test() sits between the updates.
+    X = _grid()
+    res = {}
+    for lazy in (True, False):
+        gm = gpismap_amd.GPisMap3()
+        gm.set_lazy_inverse(lazy)
+        gm.set_profile(True)
+        outs = []
+        for f in range(4):
+            gm.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+            if f == 1:
+                outs.append(gm.test(X).copy())      # inverts what frames 0-1 left; frames 2-3 retrain and go stale again
+        gm.prepare_test()
+        s = gm.stats()
+        outs.append(gm.test(X).copy())
+        res[lazy] = (outs, s["last_inverse_jobs"])
+    for a, b in zip(res[True][0], res[False][0]):
+        assert np.array_equal(a, b)
+    assert res[True][1] > 0 and res[False][1] == 0       # the deferred pass had work only in lazy mode
