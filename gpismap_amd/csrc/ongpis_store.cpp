@@ -505,11 +505,9 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         const int ctl[4] = {0, debug_inject, wait_limit_ticks, 0};
         GPIS_HIP(hipMemcpyAsync(d_err_, ctl, sizeof(ctl), hipMemcpyHostToDevice, s));
     }
-    if (nsep > 0) {
-        ongpis_launch_gather(d_models_, d_jobs_, nsep, d_ids_, pts_.d, pts_.cap, s);
-        ongpis_launch_buildK(d_models_, d_jobs_, nsep, s);
-    }
-    // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream
+    // fork: groups 1 and 2 on side streams, group 0 (or the first non-empty group) on the caller's stream.  Every group
+    // gathers and builds its OWN kernel matrices at the head of its chain (one launch over all clusters kept the largest
+    // clusters waiting for the kernel matrices of all the others: 1.3 ms in front of the cooperative factorisation).
     GPIS_HIP(hipEventRecord(evf_, s));
     hipStream_t gs[3] = {s, s3_, s2_};
     bool fused_launched = false;
@@ -535,6 +533,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         const int nbeg = gbeg[grp], ncnt = gbeg[grp + 1] - gbeg[grp];
         if (ncnt <= 0) continue;
         if (grp > 0) GPIS_HIP(hipStreamWaitEvent(gs[grp], evf_, 0));
+        ongpis_launch_gather(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_ids_, pts_.d, pts_.cap, gs[grp]);
+        ongpis_launch_buildK(d_models_, d_jobs_ + 4 * nbeg, ncnt, gs[grp]);
         if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.

@@ -6,12 +6,13 @@ OUT=gpurun_out/k3_sweep.txt
 : > $OUT
 touch gpismap_amd/csrc/ongpis_store.cpp gpismap_amd/csrc/gpismap3.cpp
 make -C gpismap_amd/csrc EXTRA=-DGPIS_INSTRUMENT > /tmp/mk.log 2>&1 || { tail -20 /tmp/mk.log; exit 1; }
-run() { echo "== $*" >> $OUT; env "$@" python3 tools/update_profile.py 6 2>/dev/null | grep "^frame [2345]" | sed 's/| pts.*//; s/preproc.*gps/gps/' >> $OUT; }
+run() { echo "== $*" >> $OUT; env "$@" python3 tools/update_profile.py 8 2>/dev/null | grep "^frame [234567]" | sed 's/| pts.*//; s/.*K3 device/K3/; s/)//' | tr '\n' ' ' >> $OUT; echo >> $OUT; }
 run K3_MAXWG=240
-run K3_MAXWG=480
-run K3_MAXWG=480 K3_MINNB=40
-run K3_MAXWG=480 K3_GMAX=4
-run K3_MAXWG=480 K3_GDIV=1400
-run K3_MAXWG=360
-run K3_MAXWG=480 K3_MINNB=24
+run K3_MAXWG=192
+run K3_MAXWG=160
+run K3_MAXWG=128
+run K3_MAXWG=96
+run K3_MAXWG=160 K3_MINNB=40
+run K3_MAXWG=128 K3_MINNB=48
+run K3_MAXWG=240
 cat $OUT
