@@ -295,6 +295,9 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
 #ifndef K3_T0_NT
 #define K3_T0_NT 3      // tiles per wavefront and round, 8-wavefront tier
 #endif
+#ifndef K3_T0_NW
+#define K3_T0_NW 8      // wavefronts per cluster, one-workgroup tier (4: two clusters per CU side by side -- measured below)
+#endif
 #ifndef K3_T0_MINW
 #define K3_T0_MINW 2    // wavefronts per SIMD the 8-wavefront tier is compiled for (2: 256 VGPRs, one workgroup per CU)
 #endif
@@ -308,7 +311,7 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
 #define K3_T1_MINW 2    // wavefronts per SIMD the one-wavefront tier is compiled for
 #endif
 template <int NT, int NW>
-__global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : K3_T0_MINW) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
+__global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : (NW == 4 ? 2 : K3_T0_MINW)) void ongpis_chol_kernel(const ClusterModel* __restrict__ models,
                                                               const int* __restrict__ d_jobs) {
     __shared__ __attribute__((aligned(16))) float D[32 * 33];       // diagonal tile, row-major padded (factor workspace)
     __shared__ __attribute__((aligned(16))) float Lc[32 * 32];      // factored diagonal tile, column-major (for the solves)
@@ -1044,7 +1047,7 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     // tier by cluster size: 0: 8 waves per workgroup; 1 (K <= 256): one wave, eight workgroups per CU -- a small
     // factorisation has too few tiles per block column to occupy more (4 waves for K <= 512 measured no better than 8)
     if (tier == 1) hipLaunchKernelGGL((ongpis_chol_kernel<K3_T1_NT, K3_T1_NW>), dim3(njobs), dim3(64 * K3_T1_NW), 0, s, d_models, d_jobs);
-    else hipLaunchKernelGGL((ongpis_chol_kernel<K3_T0_NT, 8>), dim3(njobs), dim3(512), 0, s, d_models, d_jobs);
+    else hipLaunchKernelGGL((ongpis_chol_kernel<K3_T0_NT, K3_T0_NW>), dim3(njobs), dim3(64 * K3_T0_NW), 0, s, d_models, d_jobs);
 }
 
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
