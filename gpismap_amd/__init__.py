@@ -103,6 +103,7 @@ def lib():
     L.gpis_ongpis_set_small_kernel.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_lazy_inverse.argtypes = [vp, C.c_int]
+    L.gpis_ongpis_set_async_chol.argtypes = [vp, C.c_int]
     L.gpis3_prepare_test.argtypes = [vp]
     L.gpis3_set_lazy_inverse.argtypes = [vp, C.c_int]
     _lib = L
@@ -449,6 +450,9 @@ class OnGPIS:
 
     def set_lazy_inverse(self, on=True):
         _check(self.L.gpis_ongpis_set_lazy_inverse(self.h, 1 if on else 0), "gpis_ongpis_set_lazy_inverse")
+
+    def set_async_chol(self, on=True):
+        _check(self.L.gpis_ongpis_set_async_chol(self.h, 1 if on else 0), "gpis_ongpis_set_async_chol")
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

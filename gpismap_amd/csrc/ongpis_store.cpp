@@ -536,6 +536,7 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         ongpis_launch_gather(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_ids_, pts_.d, pts_.cap, gs[grp]);
         ongpis_launch_buildK(d_models_, d_jobs_ + 4 * nbeg, ncnt, gs[grp]);
         if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
+        else if (grp == 1 && use_async_chol) ongpis_launch_chol_async(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_err_, gs[grp]);
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
         if (!lazy) ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], d_err_, gs[grp]);

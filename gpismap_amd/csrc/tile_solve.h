@@ -85,4 +85,61 @@ __device__ __forceinline__ void factor32_inreg(float (&a)[32], int row) {
     }
 }
 
+__device__ __forceinline__ float lo_half(float x) {   // the value of lane (l & 31) in every lane
+    const unsigned u = __float_as_uint(x);
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[0]);
+}
+__device__ __forceinline__ float hi_half(float x) {   // the value of lane 32 + (l & 31) in every lane
+    const unsigned u = __float_as_uint(x);
+    return __uint_as_float(__builtin_amdgcn_permlane32_swap(u, u, false, false)[1]);
+}
+
+
+// Factorisation of a 32 x 32 diagonal tile, same operations in the same order as factor32_inreg (above), in four
+// micro-blocks of eight columns.  The tile stays in ACCUMULATOR layout (t: lane = row, 16 of the 32 columns per lane
+// half); per micro-block the eight columns are pulled into every lane of their row (a8, cross-half swaps), factorised
+// column by column (pivot sqrt, column division, fmaf updates INSIDE the micro-block: 28 instead of ~200 broadcast /
+// fmaf pairs), stored column-major into Lc (zeros above the diagonal), and then folded into the rest of the tile by
+// FOUR matrix instructions: t -= l l^T over the eight columns in ascending order -- for every element the same
+// fmaf(-l_ic, l_kc, .) chain over ascending c as the scalar sweep (v_mfma_f32_32x32x2_f32 is that chain).  Entries of t
+// in or left of the micro-block are dead afterwards (never read again); entries above the diagonal are scratch.
+template <int M>
+__device__ __forceinline__ void factor32_mb(f32x16& t, int row, int h, int lane, float* Lc) {
+    float a8[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a8[i] = lo_half(t[4 * M + i]); a8[4 + i] = hi_half(t[4 * M + i]); }   // columns 8M .. 8M+7 of row `row`
+    float d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[0]), 8 * M)));
+    float lic = a8[0] / d;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const int col = 8 * M + c;
+        a8[c] = (row == col) ? d : lic;
+        if (lane < 32) Lc[col * 32 + lane] = (row >= col) ? a8[c] : 0.f;
+        const float nl = -lic;
+        float dn = 0.f, licn = 0.f;
+        if (c + 1 < 8) {
+            const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c]), col + 1));
+            a8[c + 1] = fmaf(nl, lk1, a8[c + 1]);
+            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c + 1]), col + 1)));
+            licn = a8[c + 1] / dn;
+        }
+#pragma unroll
+        for (int k = c + 2; k < 8; ++k) {
+            const float lkc = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c]), 8 * M + k));
+            a8[k] = fmaf(nl, lkc, a8[k]);
+        }
+        d = dn; lic = licn;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (M < 3) {
+        // rank-8 update of the tile: A operand and B operand are the same register (t is symmetric in its roles: element
+        // (i, k) -= l_ic l_kc); lane half h supplies the columns of parity h
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float x = h ? a8[2 * i + 1] : a8[2 * i];
+            t = __builtin_amdgcn_mfma_f32_32x32x2f32(-x, x, t, 0, 0, 0);
+        }
+    }
+}
+
 }  // namespace gpis
