@@ -26,7 +26,9 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
     return GPIS_OK;
 }
 
-OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {}
+OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {
+    if (const char* e = getenv("GPIS_ASYNC_CHOL")) use_async_chol = atoi(e) != 0;     // (opt-in K3 variant, ongpis.h)
+}
 
 OnGPISStore::~OnGPISStore() {
     clear();
