@@ -24,6 +24,9 @@ struct ObsGPView {
 
 void obsgp_launch_train(const ObsGPView& v, hipStream_t s);
 void obsgp_launch_query(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s);
+// the same answers with the queries sorted by group on the device first (counting sort; scratch: 2 nq + 2 (ngroups + 1) ints):
+// a wave then meets one or two groups instead of every group of its 64 consecutive queries
+void obsgp_launch_query_binned(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, int* scratch, hipStream_t s);
 
 // Device-resident ObsGP.  train*() re-trains every group from host inputs
 // (reference GPisMap3::regressObs, GPisMap3.cpp:239-256); query() answers a batch
@@ -91,6 +94,9 @@ private:
     int cap_qb_ = 0, cap_hqb_ = 0;
     hipEvent_t evb_ = nullptr;
     bool b_pending_ = false;
+    int* d_bin_[2] = {nullptr, nullptr};     // scratch of the device-side sort by group, one per staging set
+    size_t cap_bin_[2] = {0, 0};
+    int launch_query(int set, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s);
 };
 
 }  // namespace gpis

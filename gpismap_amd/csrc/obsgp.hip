@@ -151,24 +151,30 @@ __device__ __forceinline__ int obsgp_lookup1(const ObsGPView& v, float q0) {
 // once per (wavefront, group) instead of once per query, and the substitution costs ~45 instructions per query instead of
 // ~1200.  update()'s batches are coherent (the 7 queries of a pixel and its neighbours share a group), so a wavefront
 // usually sees one to three groups.  Worst case (64 different groups) it degenerates to one group per pass.
+// PERM: the wave takes the queries perm[64 b .. 64 b + 63] (queries sorted by group on the device: obsgp_bin_* below), so that a
+// wave meets one or two groups instead of every group its 64 consecutive queries happen to fall into; lanes are independent,
+// so the order does not touch any result.  ngq = number of queries that have a group (the sorted list's length).
+template <bool PERM>
 __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
-                                                         float* __restrict__ val, float* __restrict__ var) {
+                                                         float* __restrict__ val, float* __restrict__ var,
+                                                         const int* __restrict__ perm, const int* __restrict__ gq, const int* __restrict__ ngq) {
     // one 16 KB buffer, used twice per group: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those
     // are in registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j))
     __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
     __shared__ __attribute__((aligned(16))) float sx[128];
     __shared__ __attribute__((aligned(16))) float sa[64];
     const int lane = threadIdx.x;
-    const int qi = blockIdx.x * 64 + lane;
-    const bool have = qi < nq;
+    const int slot = blockIdx.x * 64 + lane;
+    const bool have = PERM ? (slot < *ngq) : (slot < nq);
+    const int qi = PERM ? (have ? perm[slot] : 0) : slot;
     float q0 = 0.f, q1 = 0.f;
     if (have) {
         if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
         else q0 = q[qi];
     }
     int g = -1;
-    if (have) g = (v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0);
-    if (have && g < 0) var[qi] = 1e6f;
+    if (have) g = PERM ? gq[qi] : ((v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0));
+    if (!PERM && have && g < 0) var[qi] = 1e6f;
     bool pending = have && g >= 0;
     const float a = 1 / OU_SCALE;
     for (;;) {
@@ -232,9 +238,53 @@ __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const floa
 void obsgp_launch_train(const ObsGPView& v, hipStream_t s) {
     hipLaunchKernelGGL(obsgp_train_kernel, dim3(v.ngroups), dim3(64), 0, s, v);
 }
+
+// ---- queries sorted by group on the device (counting sort: group of every query, histogram, scan, scatter) ----
+// cnt: [ngroups + 1] zeroed; gq: [nq] group of the query or -1 (those get var = 1e6 here: ObsGP.cpp:363)
+__global__ __launch_bounds__(256) void obsgp_bin_count_kernel(ObsGPView v, const float* __restrict__ q, int nq, int* __restrict__ gq,
+                                                              int* __restrict__ cnt, float* __restrict__ var) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const int g = (v.mode == 2) ? obsgp_lookup2(v, q[2 * qi], q[2 * qi + 1]) : obsgp_lookup1(v, q[qi]);
+    gq[qi] = g;
+    if (g < 0) var[qi] = 1e6f;
+    else atomicAdd(&cnt[g], 1);
+}
+// exclusive scan of cnt[0 .. n) in place (one workgroup), total -> cnt[n]; fill[] zeroed for the scatter
+__global__ __launch_bounds__(1024) void obsgp_bin_scan_kernel(int* __restrict__ cnt, int n) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = tid * per, e = min(n, b + per);
+    int sum = 0;
+    for (int i = b; i < e; ++i) sum += cnt[i];
+    part[tid] = sum;
+    __syncthreads();
+    if (tid == 0) { int run = 0; for (int i = 0; i < 1024; ++i) { const int t = part[i]; part[i] = run; run += t; } cnt[n] = run; }
+    __syncthreads();
+    int run = part[tid];
+    for (int i = b; i < e; ++i) { const int t = cnt[i]; cnt[i] = run; run += t; }
+}
+__global__ __launch_bounds__(256) void obsgp_bin_scatter_kernel(const int* __restrict__ gq, int nq, const int* __restrict__ base, int* __restrict__ fill,
+                                                                int* __restrict__ perm) {
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= nq) return;
+    const int g = gq[qi];
+    if (g >= 0) perm[base[g] + atomicAdd(&fill[g], 1)] = qi;
+}
+
 void obsgp_launch_query(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s) {
-    if (nq <= 0) return;
-    hipLaunchKernelGGL(obsgp_query_kernel, dim3((nq + 63) / 64), dim3(64), 0, s, v, d_q, nq, d_val, d_var);
+    hipLaunchKernelGGL(obsgp_query_kernel<false>, dim3((nq + 63) / 64), dim3(64), 0, s, v, d_q, nq, d_val, d_var, (const int*)nullptr, (const int*)nullptr, (const int*)nullptr);
+}
+// scratch: 2 nq + 2 (ngroups + 1) ints
+void obsgp_launch_query_binned(const ObsGPView& v, const float* d_q, int nq, float* d_val, float* d_var, int* scratch, hipStream_t s) {
+    int* gq = scratch; int* perm = gq + nq; int* cnt = perm + nq; int* fill = cnt + (v.ngroups + 1);
+    (void)hipMemsetAsync(cnt, 0, sizeof(int) * 2 * (size_t)(v.ngroups + 1), s);
+    hipLaunchKernelGGL(obsgp_bin_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, v, d_q, nq, gq, cnt, d_var);
+    hipLaunchKernelGGL(obsgp_bin_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, v.ngroups);
+    hipLaunchKernelGGL(obsgp_bin_scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, gq, nq, cnt, fill, perm);
+    // (the sorted list holds at most nq queries; waves beyond its length find nothing to do)
+    hipLaunchKernelGGL(obsgp_query_kernel<true>, dim3((nq + 63) / 64), dim3(64), 0, s, v, d_q, nq, d_val, d_var, perm, gq, cnt + v.ngroups);
 }
 
 }  // namespace gpis

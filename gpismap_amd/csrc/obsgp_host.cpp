@@ -2,6 +2,7 @@
 // the 2-D tiling, :85-143 for the 1-D groups), buffer management, H2D/D2H.
 #include <cstring>
 #include <map>
+#include <set>
 #include <vector>
 #include <algorithm>
 #include "obsgp.h"
@@ -9,16 +10,24 @@
 namespace gpis {
 
 // ---------------------------------------------------------------- DevPool ----
-// Size-class free lists over large device chunks: a block is carved from the current chunk (bump pointer) the
-// first time its class is needed and recycled through its class list afterwards -- one hipMalloc per 256 MiB
-// instead of one per cluster model (the first frame allocates several hundred models).
+// Best-fit allocator with splitting and coalescing over large device chunks (one hipMalloc per 512 MiB, not one per
+// cluster model).  Round 1-2 used exact size classes: a cluster model that grows by a few percent per frame (the usual
+// case) left its class at every retraining, its freed block matched nobody, and the pool grew by 2-4 GB per frame on the
+// synthetic sequence (25 GB after ten frames for ~5 GB of live models, a 256 MiB hipMalloc every few dozen models).  Freed
+// neighbours now merge, so the blocks the shrinking-and-growing population leaves behind are found again.
 struct DevPool {
-    std::multimap<size_t, void*> free_;
+    std::map<char*, size_t> free_addr_;            // free blocks by address (for merging)
+    std::multimap<size_t, char*> free_size_;       // the same blocks by size (best fit)
     std::map<void*, size_t> live_;
     std::vector<void*> chunks_;
-    char* cur_ = nullptr;
-    size_t left_ = 0;
+    std::set<char*> chunk_base_;                   // blocks never merge across two hipMalloc regions
     size_t bytes = 0;
+    void drop_free(char* a, size_t sz) {
+        free_addr_.erase(a);
+        auto r = free_size_.equal_range(sz);
+        for (auto it = r.first; it != r.second; ++it) if (it->second == a) { free_size_.erase(it); break; }
+    }
+    void add_free(char* a, size_t sz) { free_addr_[a] = sz; free_size_.insert({sz, a}); }
 };
 DevPool* pool_create() { return new DevPool(); }
 void pool_destroy(DevPool* p) {
@@ -26,42 +35,45 @@ void pool_destroy(DevPool* p) {
     for (void* c : p->chunks_) (void)hipFree(c);
     delete p;
 }
-static size_t pool_class(size_t b) {  // 256 KiB granules above 1 MiB, 4 KiB below
-    size_t g = b > (1u << 20) ? (256u << 10) : (4u << 10);
-    return (b + g - 1) / g * g;
-}
 void* pool_alloc(DevPool* p, size_t bytes) {
-    size_t c = pool_class(bytes ? bytes : 1);
-    auto it = p->free_.find(c);
-    void* ptr = nullptr;
-    if (it != p->free_.end()) { ptr = it->second; p->free_.erase(it); }
-    else {
-        if (c > p->left_) {
-            // the rest of the old chunk stays usable for small classes through the free lists
-            while (p->left_ >= (4u << 10)) {
-                size_t piece = p->left_ >= (256u << 10) ? (256u << 10) : (4u << 10);
-                p->free_.insert({piece, p->cur_});
-                p->cur_ += piece; p->left_ -= piece;
-            }
-            const size_t chunk = std::max<size_t>(c, (size_t)256 << 20);
-            void* base = nullptr;
-            if (hipMalloc(&base, chunk) != hipSuccess) return nullptr;
-            p->chunks_.push_back(base);
-            p->cur_ = (char*)base; p->left_ = chunk;
-            p->bytes += chunk;
-        }
-        ptr = p->cur_;
-        p->cur_ += c; p->left_ -= c;
+    constexpr size_t kGran = 4u << 10, kMinSplit = 64u << 10, kChunk = (size_t)512 << 20;
+    size_t c = ((bytes ? bytes : 1) + kGran - 1) / kGran * kGran;
+    auto it = p->free_size_.lower_bound(c);
+    if (it == p->free_size_.end()) {
+        const size_t chunk = std::max(c, kChunk);
+        void* base = nullptr;
+        if (hipMalloc(&base, chunk) != hipSuccess) return nullptr;
+        p->chunks_.push_back(base);
+        p->chunk_base_.insert((char*)base);
+        p->bytes += chunk;
+        p->add_free((char*)base, chunk);
+        it = p->free_size_.lower_bound(c);
     }
-    p->live_[ptr] = c;
-    return ptr;
+    char* a = it->second;
+    const size_t sz = it->first;
+    p->drop_free(a, sz);
+    if (sz - c >= kMinSplit) p->add_free(a + c, sz - c);
+    else c = sz;
+    p->live_[a] = c;
+    return a;
 }
 void pool_free(DevPool* p, void* ptr) {
     if (!ptr) return;
     auto it = p->live_.find(ptr);
     if (it == p->live_.end()) return;
-    p->free_.insert({it->second, ptr});
+    char* a = (char*)ptr;
+    size_t sz = it->second;
     p->live_.erase(it);
+    auto nx = p->free_addr_.find(a + sz);                       // merge with the free block behind it
+    if (nx != p->free_addr_.end() && !p->chunk_base_.count(nx->first)) { const size_t nsz = nx->second; p->drop_free(a + sz, nsz); sz += nsz; }
+    if (!p->chunk_base_.count(a)) {                             // merge with the free block in front of it
+        auto pv = p->free_addr_.lower_bound(a);
+        if (pv != p->free_addr_.begin()) {
+            --pv;
+            if (pv->first + pv->second == a) { char* pa = pv->first; const size_t psz = pv->second; p->drop_free(pa, psz); a = pa; sz += psz; }
+        }
+    }
+    p->add_free(a, sz);
 }
 size_t pool_bytes(DevPool* p) { return p->bytes; }
 
@@ -76,7 +88,7 @@ ObsGPDevice::~ObsGPDevice() {
     (void)hipHostFree(h_q_); (void)hipHostFree(h_val_); (void)hipHostFree(h_var_);
     if (b_pending_) (void)hipEventSynchronize(evb_);
     (void)hipHostFree(hb_q_); (void)hipHostFree(hb_val_); (void)hipHostFree(hb_var_);
-    (void)hipFree(db_q_); (void)hipFree(db_val_); (void)hipFree(db_var_);
+    (void)hipFree(db_q_); (void)hipFree(db_val_); (void)hipFree(db_var_); (void)hipFree(d_bin_[0]); (void)hipFree(d_bin_[1]);
     if (evb_) (void)hipEventDestroy(evb_);
     (void)hipFree(view_.tn); (void)hipFree(view_.tx); (void)hipFree(view_.talpha); (void)hipFree(view_.tL);
 }
@@ -221,7 +233,7 @@ int ObsGPDevice::train1d(const float* xt, const float* f, int N, hipStream_t s) 
 
 int ObsGPDevice::query_device(const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s) {
     if (!trained_) return GPIS_ERR_STATE;
-    obsgp_launch_query(view_, d_q, nq, d_val, d_var, s);
+    { const int lrc = launch_query(0, d_q, nq, d_val, d_var, s); if (lrc) return lrc; }
     GPIS_HIP(hipGetLastError());
     return GPIS_OK;
 }
@@ -234,7 +246,7 @@ int ObsGPDevice::query(const float* q, int nq, float* val, float* var, hipStream
     int per = (view_.mode == 2) ? 2 : 1;
     GPIS_HIP(hipMemcpyAsync(d_q_, q, sizeof(float) * per * (size_t)nq, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_val_, val, sizeof(float) * (size_t)nq, hipMemcpyHostToDevice, s));
-    obsgp_launch_query(view_, d_q_, nq, d_val_, d_var_, s);
+    { const int lrc = launch_query(0, d_q_, nq, d_val_, d_var_, s); if (lrc) return lrc; }
     GPIS_HIP(hipGetLastError());
     GPIS_HIP(hipMemcpyAsync(val, d_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipMemcpyAsync(var, d_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
@@ -264,7 +276,7 @@ int ObsGPDevice::query_staged(int nq, hipStream_t s) {
     const int per = (view_.mode == 2) ? 2 : 1;
     GPIS_HIP(hipMemcpyAsync(d_q_, h_q_, sizeof(float) * per * (size_t)nq, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemsetAsync(d_val_, 0, sizeof(float) * (size_t)nq, s));
-    obsgp_launch_query(view_, d_q_, nq, d_val_, d_var_, s);
+    { const int lrc = launch_query(0, d_q_, nq, d_val_, d_var_, s); if (lrc) return lrc; }
     GPIS_HIP(hipGetLastError());
     GPIS_HIP(hipMemcpyAsync(h_val_, d_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipMemcpyAsync(h_var_, d_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
@@ -295,6 +307,21 @@ int ObsGPDevice::get_group(int g, int* n, float* x, float* alpha, float* L, hipS
 }  // namespace gpis
 
 namespace gpis {
+
+// K2 launch: batches of kBinMin queries or more are sorted by group on the device first (obsgp.hip)
+int ObsGPDevice::launch_query(int set, const float* d_q, int nq, float* d_val, float* d_var, hipStream_t s) {
+    constexpr int kBinMin = 4096;
+    if (nq < kBinMin) { obsgp_launch_query(view_, d_q, nq, d_val, d_var, s); return GPIS_OK; }
+    const size_t need = 2 * (size_t)nq + 2 * (size_t)(view_.ngroups + 1);
+    if (need > cap_bin_[set]) {
+        (void)hipFree(d_bin_[set]); d_bin_[set] = nullptr; cap_bin_[set] = 0;
+        const size_t cap = 2 * need + 4096;
+        GPIS_HIP(hipMalloc(&d_bin_[set], sizeof(int) * cap));
+        cap_bin_[set] = cap;
+    }
+    obsgp_launch_query_binned(view_, d_q, nq, d_val, d_var, d_bin_[set], s);
+    return GPIS_OK;
+}
 
 float* ObsGPDevice::stage_qb(int nq) {
     if (b_pending_) (void)wait_b();
@@ -327,7 +354,7 @@ int ObsGPDevice::query_staged_b_async(int nq, hipStream_t s) {
     const int per = (view_.mode == 2) ? 2 : 1;
     GPIS_HIP(hipMemcpyAsync(db_q_, hb_q_, sizeof(float) * per * (size_t)nq, hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemsetAsync(db_val_, 0, sizeof(float) * (size_t)nq, s));
-    obsgp_launch_query(view_, db_q_, nq, db_val_, db_var_, s);
+    { const int lrc = launch_query(1, db_q_, nq, db_val_, db_var_, s); if (lrc) return lrc; }
     GPIS_HIP(hipGetLastError());
     GPIS_HIP(hipMemcpyAsync(hb_val_, db_val_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipMemcpyAsync(hb_var_, db_var_, sizeof(float) * (size_t)nq, hipMemcpyDeviceToHost, s));

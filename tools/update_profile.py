@@ -10,6 +10,6 @@ for f in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     d = replay.synthetic_depth(f)
     t0 = time.perf_counter(); gm.update(d, replay.IDENTITY_POSE); dt = (time.perf_counter() - t0) * 1e3
     s = gm.stats()
-    print("frame %d: %.1f ms | preproc %.1f obsgp_train %.1f reeval %.1f eval %.1f gps %.1f (K3 device %.1f) | pts %d clusters %d late %d"
+    print("frame %d: %.1f ms | preproc %.1f obsgp_train %.1f reeval %.1f eval %.1f gps %.1f (K3 device %.1f) | pts %d clusters %d late %d | model pool %.2f GB"
           % (f, dt, s["upd_preproc_ms"], s["upd_obsgp_train_ms"], s["upd_reeval_ms"], s["upd_eval_ms"], s["upd_gps_ms"], s["last_train_ms"],
-             gm.num_points(), s["clusters"], s["late_reevals"]))
+             gm.num_points(), s["clusters"], s["late_reevals"], s["device_bytes"] / 1e9))
