@@ -295,6 +295,9 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
 #ifndef K3_T0_NT
 #define K3_T0_NT 3      // tiles per wavefront and round, 8-wavefront tier
 #endif
+#ifndef K3_ASYNC_MINW
+#define K3_ASYNC_MINW 2   // waves per SIMD the barrier-free kernel is compiled for (4: 128 VGPRs, two workgroups per CU, single-row chains)
+#endif
 #ifndef K3_T0_NW
 #define K3_T0_NW 8      // wavefronts per cluster, one-workgroup tier (4: two clusters per CU side by side -- measured below)
 #endif
@@ -787,7 +790,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 // of column j is reused by column j + 4: its owner waits until every wave has left column j (progress words).
 // Same fmaf chains in the same order as the barrier kernel: bit-identical L, alpha.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void ongpis_chol_async_kernel(const ClusterModel* __restrict__ models, const int* __restrict__ d_jobs,
+__global__ __launch_bounds__(512, K3_ASYNC_MINW) void ongpis_chol_async_kernel(const ClusterModel* __restrict__ models, const int* __restrict__ d_jobs,
                                                                  int* __restrict__ ctl) {
     constexpr int NW = 8, RING = 4;
     __shared__ __attribute__((aligned(16))) float D[32 * 33];
@@ -889,7 +892,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_async_kernel(const Cluster
         }
     };
     auto finish = [&](f32x16& acc, int bi, int j, const float* Lc) __attribute__((always_inline)) {
-        diag_solve32<true>(acc, Lc, h);
+        diag_solve32<K3_ASYNC_MINW == 2>(acc, Lc, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
         float* T = Tt[wave];
@@ -963,6 +966,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_async_kernel(const Cluster
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
                 volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
+#pragma unroll 1
                 for (int c = 0; c < pw; ++c) {
                     float d = sqrtf(Dv[c * 33 + c]);
                     float lij = 0.f;
@@ -978,10 +982,11 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_async_kernel(const Cluster
                 }
                 __builtin_amdgcn_wave_barrier();
                 if (lane < 32) {
-                    for (int c = 0; c < 32; ++c) {
+#pragma unroll 1
+                    for (int c = 0; c < 32; ++c) {     // (rolled, stores through the buffer resource: 32 hoisted 64-bit addresses are 64 VGPRs)
                         float v = Dv[lane * 33 + c];
                         Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
-                        if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
+                        if (c < pw && c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
                     }
                 }
             }
@@ -992,22 +997,37 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_async_kernel(const Cluster
             f32x16 x;
 #pragma unroll
             for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
-            diag_solve32<true>(x, Lc, h);
-            float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
+            diag_solve32<K3_ASYNC_MINW == 2>(x, Lc, h);
+            // (through the buffer resource: one VGPR byte offset per lane + scalar offsets -- sixteen 64-bit addresses are hoisted and spilled)
+            const int dvoff = ((((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3)) + 16 * h) * 4;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[r]), Trs, dvoff, tri_index(j, j) * 4096 + ((r & 3) + 8 * (r >> 2)) * 16, 0);
         }
         if (first < nbr) {
-            if (!owner) { ok = wait_ge(0, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-            if (bi1 < nbr) chain2(acc0, acc1, bi0, bi1, j);
-            else chain(acc0, bi0, j);
-            if (!owner) { ok = wait_ge(1, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-            finish(acc0, bi0, j, Lc);
-            if (bi1 < nbr) finish(acc1, bi1, j, Lc);
-            for (int bi = bi1 + NW; bi < nbr; bi += NW) {     // (more than two rows per wave: the rest without look-ahead)
-                f32x16 acc;
-                chain(acc, bi, j);
-                finish(acc, bi, j, Lc);
+            if (K3_ASYNC_MINW == 2) {
+                if (!owner) { ok = wait_ge(0, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+                if (bi1 < nbr) chain2(acc0, acc1, bi0, bi1, j);
+                else chain(acc0, bi0, j);
+                if (!owner) { ok = wait_ge(1, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+                finish(acc0, bi0, j, Lc);
+                if (bi1 < nbr) finish(acc1, bi1, j, Lc);
+                for (int bi = bi1 + NW; bi < nbr; bi += NW) {     // (more than two rows per wave: the rest without look-ahead)
+                    f32x16 acc;
+                    chain(acc, bi, j);
+                    finish(acc, bi, j, Lc);
+                }
+            } else {
+                // lean variant (128 VGPRs, two workgroups per CU): one row at a time, ONE instance of chain and finish; the
+                // other workgroup of the CU fills the matrix pipe while this wave solves or waits
+                if (!owner) { ok = wait_ge(0, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#pragma unroll 1
+                for (int bi = first; bi < nbr; bi += NW) {
+                    chain(acc0, bi, j);
+                    if (bi == first && !owner) { ok = wait_ge(1, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+                    finish(acc0, bi, j, Lc);
+                }
+                if (!ok) break;
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);                      // (this wave's reads of the ring slot are done)
