@@ -89,3 +89,20 @@ def test_lazy_inverse_equals_eager():
     for a, b in zip(res[True][0], res[False][0]):
         assert np.array_equal(a, b)
     assert res[True][1] > 0 and res[False][1] == 0       # the deferred pass had work only in lazy mode
+
+
+def test_reset_and_destroy_join_the_training_in_flight():
+    # a pipelined update() leaves the factorisations running: reset() and the destructor must join them before any memory goes
+    gm = gpismap_amd.GPisMap3()
+    gm.set_pipeline(True)
+    gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    gm.reset()                                  # training of frame 0 possibly still in flight
+    assert gm.num_points() == 0
+    gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    n = gm.num_points()
+    assert n > 0
+    gm.update(replay.synthetic_depth(1), replay.IDENTITY_POSE)
+    del gm                                      # destructor with a batch in flight
+    g2 = gpismap_amd.GPisMap3()
+    g2.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    assert g2.num_points() == n
