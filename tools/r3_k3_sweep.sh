@@ -6,13 +6,10 @@ OUT=gpurun_out/k3_sweep.txt
 : > $OUT
 touch gpismap_amd/csrc/ongpis_store.cpp gpismap_amd/csrc/gpismap3.cpp
 make -C gpismap_amd/csrc EXTRA=-DGPIS_INSTRUMENT > /tmp/mk.log 2>&1 || { tail -20 /tmp/mk.log; exit 1; }
-run() { echo "== $*" >> $OUT; env "$@" python3 tools/update_profile.py 8 2>/dev/null | grep "^frame [234567]" | sed 's/| pts.*//; s/.*K3 device/K3/; s/)//' | tr '\n' ' ' >> $OUT; echo >> $OUT; }
-run K3_MAXWG=240
-run K3_MAXWG=192
-run K3_MAXWG=160
-run K3_MAXWG=128
-run K3_MAXWG=96
-run K3_MAXWG=160 K3_MINNB=40
-run K3_MAXWG=128 K3_MINNB=48
-run K3_MAXWG=240
+run() { echo "== $*" >> $OUT; env "$@" python3 tools/update_profile.py ${NF:-16} 2>/dev/null | grep "^frame" | awk -v a=${F0:-8} 'NR>a' | sed 's/| pts.*//; s/.*K3 device/K3/; s/)//' | tr '\n' ' ' >> $OUT; echo >> $OUT; }
+F0=1 run K3_GDIV=900
+F0=1 run K3_GDIV=1400
+F0=1 run K3_GDIV=2000
+F0=1 run K3_GDIV=1400 K3_GMAX=4
+F0=1 run K3_MINNB=40 K3_GDIV=1400
 cat $OUT
