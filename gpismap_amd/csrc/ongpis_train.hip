@@ -684,25 +684,29 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 // (device-scope loads: the block was modified by other wavefronts of this CU after it was last read here, and
                 // the vector L1 is not refreshed by stores)
                 // (aux 16 = sc1: the device-scope load of the agent-relaxed atomic this replaces -- served by L2, not the CU's L1)
+                f32x16 t;      // the accumulated diagonal block: lane = row, 16 of the 32 columns per lane half
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    D[l31 * 33 + rowmap_t(r, h)] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
                 if (pw == 32) {
-                    const int row = lane & 31;
-                    float a[32];
-#pragma unroll
-                    for (int k = 0; k < 32; ++k) a[k] = D[row * 33 + k];
-                    factor32_inreg(a, row);
+                    // micro-blocked factorisation in accumulator layout (tile_solve.h: same operations in the same order as
+                    // factor32_inreg, the trailing updates of a micro-block as four matrix instructions): about half the cycles
+                    // of the column-by-column sweep, and it sits on the serial path of every block column
+                    factor32_mb<0>(t, l31, h, lane, Lc);
+                    factor32_mb<1>(t, l31, h, lane, Lc);
+                    factor32_mb<2>(t, l31, h, lane, Lc);
+                    factor32_mb<3>(t, l31, h, lane, Lc);
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
                     if (lane < 32) {
 #pragma unroll
-                        for (int c = 0; c < 32; ++c) {
-                            Lc[c * 32 + lane] = a[c];
-                            if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(a[c]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
-                        }
+                        for (int c = 0; c < 32; ++c)
+                            if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Lc[c * 32 + lane]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
                     }
                 } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) D[l31 * 33 + rowmap_t(r, h)] = t[r];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
                     volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
                     for (int c = 0; c < pw; ++c) {
                         float d = sqrtf(Dv[c * 33 + c]);
