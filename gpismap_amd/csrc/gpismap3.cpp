@@ -161,6 +161,8 @@ struct GPisMap3::Impl {
         if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) pipeline = atoi(e) != 0;
         if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
         if (const char* e = getenv("GPIS_EAGER_INVERSE")) if (atoi(e) != 0) store.lazy_inverse = false;
+        store.trim_scratch = true;     // a cluster keeps only what prediction reads once its inverse exists (GPIS_KEEP_FACTORS=1: keep all)
+        if (const char* e = getenv("GPIS_KEEP_FACTORS")) if (atoi(e) != 0) store.trim_scratch = false;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }

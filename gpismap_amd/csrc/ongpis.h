@@ -37,6 +37,8 @@ struct ClusterModel {
     float* sig;             // [2*N] sigx' (after the 2.0 override), sigg
     int* gidx;              // [N]   running gradient index or -1
     void* base;
+    void* scratch;          // second allocation of a fully trained model: factor, re-tiled factor, inverse scratch, training vectors
+                            // (host bookkeeping; freed after the inverse when the store trims: OnGPISStore::trim_scratch)
 };
 
 // Map-point mirror in HBM: structure of arrays, index = stable point id.
@@ -120,6 +122,11 @@ public:
     // consecutive updates is inverted once, when somebody asks (the reference's train() does not pay for prediction
     // either: OnGPIS.cpp:139-143 stops at L and alpha).  false: K3b runs behind K3 in every training batch.
     bool lazy_inverse = true;
+    // Models of more than 256 rows live in TWO allocations: what prediction reads (rowinfo, x4, Xt) and the training side (L,
+    // alpha, y, sig, gidx, Lt, Zt = 8 of their 10 K^2 bytes).  With trim_scratch the training side goes back to the pool as soon
+    // as the inverse exists (the maps set it: a cluster then holds 2 K^2 bytes between its retrainings, half of what the
+    // reference's dense L costs; gpis_ongpis_get_model needs the factor and leaves it off).
+    bool trim_scratch = false;
     int ensure_inverses(hipStream_t s);
     float last_inverse_ms = 0.f;     // K3b pass of the last ensure_inverses() that had work (profiling on)
     int last_inverse_jobs = 0;
@@ -132,6 +139,8 @@ private:
     int train_batch_impl(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s);
     void build_inverse_work(const std::vector<int>& tab, int jbeg, int jend, int kLongCol, std::vector<int>& work,
                             int& off, int& nlong, int& nmid, int& nshort) const;
+    void free_model_mem(ClusterModel& m);
+    void trim_models(const std::vector<int>& slots);
     void mark_stale(int slot) { if ((int)xstale_.size() < (int)models_.size()) xstale_.resize(models_.size(), 0); xstale_[slot] = 1; stale_list_.push_back(slot); }
     std::vector<char> xstale_;                   // per slot: the factor is newer than Xt (lazy inverse)
     std::vector<int> stale_list_;                // slots marked since the last ensure_inverses()

@@ -47,7 +47,7 @@ OnGPISStore::~OnGPISStore() {
 void OnGPISStore::clear() {
     (void)train_finish();
     for (size_t i = 0; i < models_.size(); ++i)
-        if (live_[i] && models_[i].base) pool_free(pool_, models_[i].base);
+        if (live_[i]) free_model_mem(models_[i]);
     models_.clear(); live_.clear(); free_slots_.clear();
     xstale_.clear(); stale_list_.clear();
     dirty_ = true;
@@ -67,7 +67,7 @@ void OnGPISStore::release_slot(int s) {
     if (s < 0 || s >= (int)models_.size() || !live_[s]) return;
     (void)train_finish();   // (the memory of a model of the batch in flight must not return to the pool under the kernels)
     if (s < (int)xstale_.size()) xstale_[s] = 0;
-    if (models_[s].base) pool_free(pool_, models_[s].base);
+    free_model_mem(models_[s]);
     std::memset(&models_[s], 0, sizeof(ClusterModel));
     live_[s] = 0;
     free_slots_.push_back(s);
@@ -76,13 +76,32 @@ void OnGPISStore::release_slot(int s) {
 
 size_t OnGPISStore::device_bytes() const { return pool_bytes(pool_); }
 
+void OnGPISStore::free_model_mem(ClusterModel& m) {
+    if (m.base) pool_free(pool_, m.base);
+    if (m.scratch) pool_free(pool_, m.scratch);
+    m.base = nullptr; m.scratch = nullptr;
+}
+
+// the training side of models whose inverse exists goes back to the pool (trim_scratch)
+void OnGPISStore::trim_models(const std::vector<int>& slots) {
+    for (int slot : slots) {
+        if (slot < 0 || slot >= (int)models_.size() || !live_[slot]) continue;
+        ClusterModel& m = models_[slot];
+        if (!m.scratch) continue;
+        pool_free(pool_, m.scratch);
+        m.scratch = nullptr;
+        m.L = nullptr; m.alpha = nullptr; m.y = nullptr; m.sig = nullptr; m.gidx = nullptr; m.Lt = nullptr; m.Zt = nullptr;
+        dirty_ = true;
+    }
+}
+
 int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
     ClusterModel& m = models_[slot];
     int K = N + dim_ * ng;
     int ld = (int)align_up((size_t)K + 1, 32);
     int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     const size_t szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
-    if (m.base) { pool_free(pool_, m.base); m.base = nullptr; }
+    free_model_mem(m);
     if (kind != kAllocFull) {
         // what K4 reads (rowinfo, x4, Xt): imported models and models trained by the fused on-chip kernel;
         // kAllocLeanFactor adds the factor, alpha and the gradient index for parity tests / gpis_ongpis_get_model
@@ -105,25 +124,30 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
         dirty_ = true;
         return GPIS_OK;
     }
+    // prediction side (what K4 reads) and training side in two allocations: the second one can go back to the pool once the
+    // inverse exists (trim_scratch)
+    size_t oR = 0, szR = sizeof(int) * ld;
+    size_t oX = align_up(oR + szR, 256), szX = sizeof(float) * 4 * (size_t)N;
+    size_t oXt = align_up(oX + szX, 256);
+    const size_t total_p = align_up(oXt + szT, 256);
     size_t oL = 0, szL = sizeof(float) * (size_t)ld * ld;
     size_t oA = align_up(oL + szL, 256), szA = sizeof(float) * ld;
-    size_t oX = align_up(oA + szA, 256), szX = sizeof(float) * 4 * (size_t)N;
-    size_t oR = align_up(oX + szX, 256), szR = sizeof(int) * ld;
-    size_t oY = align_up(oR + szR, 256), szY = sizeof(float) * ld;
+    size_t oY = align_up(oA + szA, 256), szY = sizeof(float) * ld;
     size_t oS = align_up(oY + szY, 256), szS = sizeof(float) * 2 * (size_t)N;
     size_t oG = align_up(oS + szS, 256), szG = sizeof(int) * (size_t)N;
     size_t oT = align_up(oG + szG, 256);
-    size_t oXt = align_up(oT + szT, 256), oZt = align_up(oXt + szT, 256);   // explicit inverse, re-tiled, and its transposed tiles
-    size_t total = align_up(oZt + szT, 256);
-    char* base = (char*)pool_alloc(pool_, total);
+    size_t oZt = align_up(oT + szT, 256);                   // transposed tiles of the inverse (K3b's B operands)
+    const size_t total_s = align_up(oZt + szT, 256);
+    char* base = (char*)pool_alloc(pool_, total_p);
     if (!base) return GPIS_ERR_HIP;
+    char* sc = (char*)pool_alloc(pool_, total_s);
+    if (!sc) { pool_free(pool_, base); return GPIS_ERR_HIP; }
     std::memset(&m, 0, sizeof(ClusterModel));
     m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
-    m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.x4 = (float*)(base + oX);
-    m.rowinfo = (int*)(base + oR); m.y = (float*)(base + oY); m.sig = (float*)(base + oS); m.gidx = (int*)(base + oG);
-    m.Lt = (float*)(base + oT);
-    m.Xt = (float*)(base + oXt); m.Zt = (float*)(base + oZt);
-    m.base = base;
+    m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
+    m.L = (float*)(sc + oL); m.alpha = (float*)(sc + oA); m.y = (float*)(sc + oY); m.sig = (float*)(sc + oS); m.gidx = (int*)(sc + oG);
+    m.Lt = (float*)(sc + oT); m.Zt = (float*)(sc + oZt);
+    m.base = base; m.scratch = sc;
     dirty_ = true;
     return GPIS_OK;
 }
@@ -348,13 +372,14 @@ int OnGPISStore::ensure_inverses(hipStream_t s) {
         fprintf(stderr, "[gpismap_amd] inverse kernels reported error word 0x%x: the %d models of this pass are dropped\n", h_err_[0], nj);
         for (int slot : slots) {
             ClusterModel& m = models_[slot];
-            if (m.base) pool_free(pool_, m.base);
+            free_model_mem(m);
             std::memset(&m, 0, sizeof(ClusterModel));
         }
         dirty_ = true;
         (void)sync_models(s);
         return GPIS_ERR_STATE;
     }
+    if (trim_scratch) trim_models(slots);      // the factors have served: their memory goes back to the pool
     return GPIS_OK;
 }
 
@@ -573,13 +598,14 @@ int OnGPISStore::train_finish() {
         for (int slot : pend_models_) {
             if (slot < 0 || slot >= (int)models_.size() || !live_[slot]) continue;
             ClusterModel& m = models_[slot];
-            if (m.base) pool_free(pool_, m.base);
+            free_model_mem(m);
             std::memset(&m, 0, sizeof(ClusterModel));
         }
         dirty_ = true;
         (void)sync_models(pend_stream_);
         return GPIS_ERR_STATE;
     }
+    if (trim_scratch && !lazy_inverse) trim_models(pend_models_);     // (eager inverse: X exists when the batch is through)
     return GPIS_OK;
 }
 
@@ -704,7 +730,7 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
         else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return bail(GPIS_ERR_ARG);
         if (absent) {                    // the owner could not train it: untrained here too (test() sees no GP in that cell)
             ClusterModel& m = models_[slots[i]];
-            if (m.base) pool_free(pool_, m.base);
+            free_model_mem(m);
             std::memset(&m, 0, sizeof(ClusterModel));
             dirty_ = true;
             continue;
