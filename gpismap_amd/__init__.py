@@ -100,10 +100,8 @@ def lib():
     L.gpis_ongpis_kernel_matrix.argtypes = [vp, fp, ip, fp, fp, C.c_int, fp]
     L.gpis_ongpis_set_debug.argtypes = [vp, C.c_int, C.c_int]
     L.gpis_ongpis_set_keep_factor.argtypes = [vp, C.c_int]
-    L.gpis_ongpis_set_small_kernel.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_lazy_inverse.argtypes = [vp, C.c_int]
-    L.gpis_ongpis_set_async_chol.argtypes = [vp, C.c_int]
     L.gpis3_prepare_test.argtypes = [vp]
     L.gpis3_set_lazy_inverse.argtypes = [vp, C.c_int]
     _lib = L
@@ -445,14 +443,8 @@ class OnGPIS:
         """Bound of the in-kernel waits (0 = default 2 s) and the test-only fault injection of the cooperative kernel."""
         _check(self.L.gpis_ongpis_set_debug(self.h, int(inject), int(wait_limit_ms)), "gpis_ongpis_set_debug")
 
-    def set_small_kernel(self, on=True):
-        _check(self.L.gpis_ongpis_set_small_kernel(self.h, 1 if on else 0), "gpis_ongpis_set_small_kernel")
-
     def set_lazy_inverse(self, on=True):
         _check(self.L.gpis_ongpis_set_lazy_inverse(self.h, 1 if on else 0), "gpis_ongpis_set_lazy_inverse")
-
-    def set_async_chol(self, on=True):
-        _check(self.L.gpis_ongpis_set_async_chol(self.h, 1 if on else 0), "gpis_ongpis_set_async_chol")
 
     def set_exp_table(self, on=True):
         _check(self.L.gpis_ongpis_set_exp_table(self.h, 1 if on else 0), "gpis_ongpis_set_exp_table")

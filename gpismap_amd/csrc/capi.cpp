@@ -322,19 +322,9 @@ int gpis_ongpis_set_fused(void* s, int on) {
     ((OnHandle*)s)->st.use_fused = on != 0;
     return GPIS_OK;
 }
-int gpis_ongpis_set_async_chol(void* s, int on) {
-    if (!s) return GPIS_ERR_ARG;
-    ((OnHandle*)s)->st.use_async_chol = on != 0;
-    return GPIS_OK;
-}
 int gpis_ongpis_set_lazy_inverse(void* s, int on) {
     if (!s) return GPIS_ERR_ARG;
     ((OnHandle*)s)->st.lazy_inverse = on != 0;
-    return GPIS_OK;
-}
-int gpis_ongpis_set_small_kernel(void* s, int on) {
-    if (!s) return GPIS_ERR_ARG;
-    ((OnHandle*)s)->st.use_small_kernel = on != 0;
     return GPIS_OK;
 }
 int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {

@@ -991,6 +991,7 @@ bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_st
     m.finish_training();
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
     if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap3::testDevice: device path failed (%d)\n", rc); }
+    if (rc == GPIS_ERR_STATE) m.build_cluster_table();   // (models dropped by the inverse pass: their cells have no GP any more)
     return rc == GPIS_OK;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::testDevice", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::testDevice", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
 
@@ -1042,7 +1043,11 @@ bool GPisMap3::test_one(float* x, int dim, int leng, float* res) try {
     if (hipMemcpyAsync(m.d_x, x, sizeof(float) * nx, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     // only some entries are written (callers pre-fill res, mexGPisMap3.cpp:99): start from the caller's buffer
     if (hipMemcpyAsync(m.d_res, res, sizeof(float) * nr, hipMemcpyHostToDevice, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
-    { const int rc = m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream); if (rc != GPIS_OK) return fail(rc); }
+    {
+        const int rc = m.mq.run(m.store, m.d_x, leng, m.d_res, m.stream);
+        if (rc == GPIS_ERR_STATE) m.build_cluster_table();   // (models dropped by the inverse pass: their cells have no GP any more)
+        if (rc != GPIS_OK) return fail(rc);
+    }
     if (hipMemcpyAsync(res, m.d_res, sizeof(float) * nr, hipMemcpyDeviceToHost, m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     if (hipStreamSynchronize(m.stream) != hipSuccess) return fail(GPIS_ERR_HIP);
     return true;
@@ -1169,11 +1174,14 @@ int gpis3_impl_prepare_test(GPisMap3* g) {
     m.finish_training();
     const int rc = m.store.ensure_inverses(m.stream);
     if (rc && !m.upd_rc) m.upd_rc = rc;
+    if (rc == GPIS_ERR_STATE && !m.table_pending) m.build_cluster_table();
     return m.upd_rc;
 }
 void gpis3_impl_set_lazy_inverse(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();
     for (GPisMap3* q : m.peers) gpis3_impl_set_lazy_inverse(q, on);
+    DeviceScope ds(m.device);
+    m.finish_training();       // a batch in flight is joined in the mode it was enqueued with
     m.store.lazy_inverse = on != 0;
 }
 void gpis3_impl_set_host_gather(GPisMap3* g, int on) {

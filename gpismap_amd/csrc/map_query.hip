@@ -532,7 +532,7 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
         EvalArgs a;
         a.models = store.d_models(); a.xq = d_xq_;
         a.tile_model = t_model + tot[8 + c]; a.tile_off = t_off + tot[8 + c]; a.tile_cnt = t_cnt + tot[8 + c];
-        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.use_small = store.use_small_kernel ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.cb = 0; a.nslot = 0; a.trace = nullptr;
         int rc = ongpis_eval_launch(c, nt, h_maxN_[c], h_maxLd_[c], a, s);
         if (rc) return rc;
     }

@@ -100,17 +100,12 @@ public:
     int last_train_jobs = 0, last_train_maxK = 0;
     long long last_eval_flops = 0;
     bool profile = false;
-    bool use_small_kernel = false;  // K4 for clusters of at most ONGPIS_SMALL_NBX block rows through the resident-X kernel (opt-in: parity-green,
-                                    // measured SLOWER than the general kernel on MI355X -- 16.1 vs 15.1 ms on the stress configuration)
     bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
     bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
                                  // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
     int debug_inject = 0;        // test-only fault injection for the cooperative kernel (ongpis_train.hip, ctl[1])
     int wait_limit_ticks = 0;    // bound of the in-kernel waits in 100 MHz ticks (0: 2 s)
     bool use_fused = true;       // false: every cluster takes the separate gather / build / factorise / invert kernels
-    bool use_async_chol = false; // one-workgroup clusters of more than 256 rows through ongpis_chol_async_kernel (rows owned by waves, LDS
-                                 // counters instead of a barrier per block column): bit-identical, measured 3-6 % faster as a kernel and
-                                 // equal on the frames -- opt-in
     // Pipelined training: train_batch() returns once the kernels are enqueued (on the caller's stream and the side streams)
     // and train_finish() joins them -- waits, reads the error word, drops the batch on error.  The map object sets this so
     // that the host work of the NEXT update() runs beside the factorisations of this one; every other entry point of the
@@ -127,6 +122,9 @@ public:
     // as the inverse exists (the maps set it: a cluster then holds 2 K^2 bytes between its retrainings, half of what the
     // reference's dense L costs; gpis_ongpis_get_model needs the factor and leaves it off).
     bool trim_scratch = false;
+    // Lazy inverse: bytes of training-side memory that models waiting for their inverse may hold before a training batch
+    // inverts and trims them (a caller that never predicts would otherwise keep 10 K^2 bytes per cluster for ever)
+    size_t stale_bytes_limit = (size_t)4 << 30;
     int ensure_inverses(hipStream_t s);
     float last_inverse_ms = 0.f;     // K3b pass of the last ensure_inverses() that had work (profiling on)
     int last_inverse_jobs = 0;
@@ -145,6 +143,9 @@ private:
     std::vector<char> xstale_;                   // per slot: the factor is newer than Xt (lazy inverse)
     std::vector<int> stale_list_;                // slots marked since the last ensure_inverses()
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
+    int train_enqueue(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
+    int coop_dev_ = 0, coop_held_ = 0;           // cooperative workgroups this store holds of its device's budget (batch in flight)
+    bool enqueued_ = false;                      // train_enqueue() got as far as handing the batch to train_finish()
     int* d_rg_ = nullptr; int cap_rg_ = 0;       // range gather: cell point lists, cell entries, cluster descriptors, counts
     int dev_ids_ = 0;                            // ids the last gather_ranges() left in d_ids_
     int dim_;
@@ -165,7 +166,7 @@ private:
     int* d_slots_ = nullptr; int cap_slots_ = 0; // pack / unpack slot list (grown on demand: no hipMalloc / hipFree per call)
     int* d_err_ = nullptr;                       // device error word of the training kernels (zeroed per batch)
     int* h_err_ = nullptr;                       // its page-locked host copy (written by the batch's last copy)
-    bool pend_active_ = false, pend_profile_ = false;   // a training batch is in flight (train_finish joins it)
+    bool pend_active_ = false, pend_profile_ = false, pend_lazy_ = false;   // a training batch is in flight (train_finish joins it)
     hipStream_t pend_stream_ = nullptr;
     std::vector<int> pend_models_;               // slots of the batch in flight
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
@@ -195,8 +196,11 @@ void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int n
 void ongpis_launch_range_gather(const int* d_desc, const int* d_cranges, const int* d_cell_pts, int nclusters, const float* d_pts, int pts_cap,
                                 int dim, int* d_ids, int* d_counts, hipStream_t s);
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
-// one workgroup per cluster, no barrier per block column: rows owned by waves, LDS counters (ongpis_chol_async_kernel)
+#ifdef GPIS_EXPERIMENTS   // tools/experiments/: archived kernels, built only with EXTRA=-DGPIS_EXPERIMENTS, selected by GPIS_ASYNC_CHOL / GPIS_SMALL_KERNEL
 void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, int njobs, int* d_ctl, hipStream_t s);
+size_t ongpis_eval_small_lds(int maxN, int maxLd);
+int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
+#endif
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup (job < 0: padding), sync = 3 ints per job (zeroed)
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
@@ -217,7 +221,6 @@ struct EvalArgs {
     const int* job_q;        // query index per job (sorted by model)
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
-    int use_small;           // classes 0..2 through the resident-X kernel (default) instead of the general one
     int use_table;           // exp table in LDS (else recompute per entry); the launcher clears it when the table does not fit
     int cb;                  // column blocks per B chunk (set by ongpis_eval_launch from the LDS budget)
     int nslot;               // chunks in the LDS ring (2 or 3)
@@ -240,8 +243,5 @@ __host__ __device__ inline int ongpis_class_of_nbx(int nbx) {
 int ongpis_eval_class(int nbx);
 bool ongpis_eval_fits(int N, int ld);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
-// classes 0..2 (at most ONGPIS_SMALL_NBX block rows): X resident in registers across consecutive tiles of a cluster
-size_t ongpis_eval_small_lds(int maxN, int maxLd);
-int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 
 }  // namespace gpis

@@ -3,6 +3,7 @@
 // entry (K4) used by the kernel-level C-ABI and the parity tests.
 #include <algorithm>
 #include <cstring>
+#include <map>
 #include <mutex>
 #include <numeric>
 #include <set>
@@ -26,8 +27,30 @@ int ensure_dynamic_lds(const void* kernel, int bytes) {
     return GPIS_OK;
 }
 
+// The cooperative factorisation waits on its partner workgroups, so every workgroup of a launch must be resident.  Several
+// stores may drive ONE device from their own host threads (GPIS_DEVICES=0,0,0; ranks sharing a GPU inside one process): they
+// share one per-device budget of cooperative workgroups.  A store takes what is free when it enqueues a batch and gives it
+// back when the batch is joined; clusters that do not fit the share take the one-workgroup kernel (same chains, same bits).
+namespace {
+std::mutex g_coop_mu;
+std::map<int, std::pair<int, int>> g_coop;   // device -> (capacity, in use)
+int coop_take_all(int dev) {
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    auto it = g_coop.find(dev);
+    if (it == g_coop.end()) it = g_coop.emplace(dev, std::make_pair(std::max(2, ongpis_coop_capacity()), 0)).first;
+    const int free_wg = std::max(0, it->second.first - it->second.second);
+    it->second.second += free_wg;
+    return free_wg;
+}
+void coop_give_back(int dev, int n) {
+    if (n <= 0) return;
+    std::lock_guard<std::mutex> lk(g_coop_mu);
+    auto it = g_coop.find(dev);
+    if (it != g_coop.end()) it->second.second = std::max(0, it->second.second - n);
+}
+}  // namespace
+
 OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {
-    if (const char* e = getenv("GPIS_ASYNC_CHOL")) use_async_chol = atoi(e) != 0;     // (opt-in K3 variant, ongpis.h)
 }
 
 OnGPISStore::~OnGPISStore() {
@@ -88,6 +111,7 @@ void OnGPISStore::trim_models(const std::vector<int>& slots) {
         if (slot < 0 || slot >= (int)models_.size() || !live_[slot]) continue;
         ClusterModel& m = models_[slot];
         if (!m.scratch) continue;
+        if (slot < (int)xstale_.size() && xstale_[slot]) continue;   // its X is still to be computed FROM this factor
         pool_free(pool_, m.scratch);
         m.scratch = nullptr;
         m.L = nullptr; m.alpha = nullptr; m.y = nullptr; m.sig = nullptr; m.gidx = nullptr; m.Lt = nullptr; m.Zt = nullptr;
@@ -230,6 +254,26 @@ int OnGPISStore::train_batch_impl(const std::vector<TrainJob>& jobs, const std::
         if (tj.model < 0 || tj.model >= (int)models_.size() || !live_[tj.model] || tj.n <= 0 || tj.ng < 0 || tj.ng > tj.n ||
             tj.off < 0 || (size_t)tj.off + (size_t)tj.n > nids)
             return GPIS_ERR_ARG;
+    }
+    // Lazy inverse: the training side of a stale model (8 K^2 of its 10 K^2 bytes) is held until its inverse has been
+    // computed.  A session that only ever calls update() would keep it for every cluster it has trained; bound that: the
+    // models of THIS batch are about to be retrained (their old factor is moot), and when what the others hold exceeds
+    // stale_bytes_limit they are inverted and trimmed now.
+    if (!stale_list_.empty()) {
+        for (int j = 0; j < nj; ++j) {
+            const int Kj = jobs[j].n + dim_ * jobs[j].ng;
+            const bool refused = Kj > ONGPIS_MAX_K || !ongpis_eval_fits(jobs[j].n, (int)align_up((size_t)Kj + 1, 32));   // (keeps its previous model, pass 2)
+            if (!refused && jobs[j].model < (int)xstale_.size()) xstale_[jobs[j].model] = 0;
+        }
+        size_t held = 0;
+        for (int slot : stale_list_)
+            if (slot >= 0 && slot < (int)xstale_.size() && xstale_[slot] && live_[slot] && models_[slot].scratch)
+                held += (size_t)8 * models_[slot].ld * models_[slot].ld;
+        if (held > stale_bytes_limit) {
+            // (duplicates in the list would be counted twice: the bound errs on the early side)
+            const int erc = ensure_inverses(s);
+            if (erc) return erc;
+        }
     }
     // Pass 2: allocate.  A cluster this build cannot hold keeps its previous model (the rest of the batch is still
     // trained and the error reported); an allocation failure leaves that model UNTRAINED (base = nullptr: test()
@@ -383,8 +427,30 @@ int OnGPISStore::ensure_inverses(hipStream_t s) {
     return GPIS_OK;
 }
 
-// K6 + kernel build + K3 for jobs whose models are allocated.
+// K6 + kernel build + K3 for jobs whose models are allocated.  An error exit BEFORE the batch is completely enqueued (a HIP
+// call, a refused fused launch) would leave models that are allocated -- base != nullptr, so a valid GP to the cluster table --
+// but never trained: whatever was launched is drained and the batch's models are marked untrained, like a dropped batch.
 int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc) {
+    enqueued_ = false;
+    const int rc = train_enqueue(jobs, ids, s, deferred_rc);
+    if (enqueued_) return rc;
+    (void)hipStreamSynchronize(s);
+    if (s2_) (void)hipStreamSynchronize(s2_);
+    if (s3_) (void)hipStreamSynchronize(s3_);
+    coop_give_back(coop_dev_, coop_held_); coop_held_ = 0;
+    fprintf(stderr, "[gpismap_amd] training batch not enqueued (%d): its %d models are dropped\n", rc, (int)jobs.size());
+    for (const TrainJob& tj : jobs) {
+        ClusterModel& m = models_[tj.model];
+        free_model_mem(m);
+        std::memset(&m, 0, sizeof(ClusterModel));
+        if (tj.model < (int)xstale_.size()) xstale_[tj.model] = 0;
+    }
+    dirty_ = true;
+    (void)sync_models(s);
+    return rc ? rc : GPIS_ERR_STATE;
+}
+
+int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc) {
     const int nj = (int)jobs.size();
     std::vector<int> tab((size_t)4 * nj);
     // largest clusters first: one workgroup per cluster and K^3 work, so the big factorisations must not start last
@@ -429,9 +495,10 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     // workgroup per cluster is faster; few workgroups per cluster (so that MANY clusters fit the launch) beat many workgroups
     // for few clusters -- a cooperative cluster is bound by its serial path, and every large cluster left to the
     // one-workgroup kernel costs more than a small G costs the largest ones.
-    static int coop_capacity = 0;    // resident workgroups of the cooperative kernel on this device (queried once)
-    if (!coop_capacity) coop_capacity = std::max(2, ongpis_coop_capacity());
-    int kCoopMinNb = 32, kCoopMaxWG = coop_capacity;
+    int coop_dev = 0;
+    (void)hipGetDevice(&coop_dev);
+    const int coop_share = coop_take_all(coop_dev);   // free cooperative workgroups of this device (per-device budget, see above)
+    int kCoopMinNb = 32, kCoopMaxWG = coop_share;
     int kCoopGDiv = 900, kCoopGMax = 6;
     int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
@@ -456,6 +523,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
             total += G;
             ncoop = j + 1;
         }
+        coop_give_back(coop_dev, coop_share - total);   // keep what the launch needs until the batch is joined
+        coop_dev_ = coop_dev; coop_held_ = total;
         size_t mx = 0;
         for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 3);
         for (size_t k = 0; k < mx && total > 0; ++k)
@@ -563,7 +632,9 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
         ongpis_launch_gather(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_ids_, pts_.d, pts_.cap, gs[grp]);
         ongpis_launch_buildK(d_models_, d_jobs_ + 4 * nbeg, ncnt, gs[grp]);
         if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
-        else if (grp == 1 && use_async_chol) ongpis_launch_chol_async(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_err_, gs[grp]);
+#ifdef GPIS_EXPERIMENTS
+        else if (grp == 1 && getenv("GPIS_ASYNC_CHOL") && atoi(getenv("GPIS_ASYNC_CHOL"))) ongpis_launch_chol_async(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_err_, gs[grp]);
+#endif
         else ongpis_launch_chol(d_models_, d_jobs_ + 4 * nbeg, ncnt, grp == 2 ? 1 : 0, gs[grp]);
         // K3b of the group: X = L^-1, re-tiled for K4.  The job index in the work list is the global one.
         if (!lazy) ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + wl_off[grp], wl_long[grp], wl_mid[grp], wl_short[grp], d_err_, gs[grp]);
@@ -576,7 +647,8 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
     if (!h_err_) GPIS_HIP(hipHostMalloc((void**)&h_err_, sizeof(int) * 4));
     for (int i = 0; i < 4; ++i) h_err_[i] = 0;
     GPIS_HIP(hipMemcpyAsync(h_err_, d_err_, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
-    pend_active_ = true; pend_profile_ = profile; pend_stream_ = s;
+    pend_active_ = true; pend_profile_ = profile; pend_stream_ = s; pend_lazy_ = lazy;
+    enqueued_ = true;
     pend_models_.resize(nj);
     for (int j = 0; j < nj; ++j) pend_models_[j] = tab[4 * j];
     if (defer_finish) return deferred_rc;
@@ -588,7 +660,9 @@ int OnGPISStore::train_allocated(const std::vector<TrainJob>& jobs, const std::v
 int OnGPISStore::train_finish() {
     if (!pend_active_) return GPIS_OK;
     pend_active_ = false;
-    GPIS_HIP(hipStreamSynchronize(pend_stream_));
+    const hipError_t se = hipStreamSynchronize(pend_stream_);
+    coop_give_back(coop_dev_, coop_held_); coop_held_ = 0;
+    GPIS_HIP(se);
     if (pend_profile_) GPIS_HIP(hipEventElapsedTime(&last_train_ms, ev0_, ev1_));
     if (h_err_[0]) {
         // bit 0: a job the fused kernel cannot hold; bit 1: a wait of the cooperative factorisation expired; bit 2: a row
@@ -605,7 +679,9 @@ int OnGPISStore::train_finish() {
         (void)sync_models(pend_stream_);
         return GPIS_ERR_STATE;
     }
-    if (trim_scratch && !lazy_inverse) trim_models(pend_models_);     // (eager inverse: X exists when the batch is through)
+    // (eager inverse: X exists when the batch is through.  The mode the batch was ENQUEUED with decides, not the current
+    // flag: a lazy batch has no X yet whatever the caller switched to since.)
+    if (trim_scratch && !pend_lazy_) trim_models(pend_models_);
     return GPIS_OK;
 }
 
@@ -826,7 +902,7 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.use_small = use_small_kernel ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
         rc = ongpis_eval_launch(c, nt, maxN[c], maxLd[c], a, s);
         if (rc) return rc;
     }

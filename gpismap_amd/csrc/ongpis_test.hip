@@ -407,9 +407,10 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     if (ntiles <= 0) return GPIS_OK;
     if (wclass < 0 || wclass >= ONGPIS_NCLASS) return GPIS_ERR_ARG;
     EvalArgs args = args_in;
-    // clusters of at most ONGPIS_SMALL_NBX block rows: the resident-X kernel (ongpis_test_small.hip), same results bit for bit
-    if (args_in.use_small && wclass <= 2 && maxLd / 32 <= ONGPIS_SMALL_NBX && ongpis_eval_small_lds(maxN, maxLd) <= (size_t)160 * 1024)
+#ifdef GPIS_EXPERIMENTS   // the archived resident-X kernel for clusters of at most ONGPIS_SMALL_NBX block rows (tools/experiments/)
+    if (getenv("GPIS_SMALL_KERNEL") && atoi(getenv("GPIS_SMALL_KERNEL")) && wclass <= 2 && maxLd / 32 <= ONGPIS_SMALL_NBX && ongpis_eval_small_lds(maxN, maxLd) <= (size_t)160 * 1024)
         return ongpis_eval_small_launch(ntiles, maxN, maxLd, args_in, s);
+#endif
     const int W = kClassW[wclass];
     // LDS budget: the register file admits kWavesPerCU wavefronts per CU, i.e. kWavesPerCU / W workgroups; give each an
     // equal share of the 160 KB and spend what the per-cluster tables leave on the ring of B chunks: NSLOT slots

@@ -780,269 +780,9 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
 }
 
-// ---------------------------------------------------------------------------
-// K3, one workgroup per cluster WITHOUT a barrier per block column (round 3).  The barrier kernel above spends three
-// quarters of every wave's time waiting: for the wave with the most tiles of the column, for the diagonal factorisation,
-// through the solves (cycle stamps, profiles/r03_k3_ablation.txt).  Here block ROW bi belongs to wave bi mod 8 for the whole
-// factorisation -- the cooperative kernel's scheme with waves in place of workgroups and two counters in LDS in place of
-// the device-scope flags:
-//   f_tiles = j + 1 : the off-diagonal tiles of row j are final (published by row j's wave before it factors L_jj)
-//   f_ready = j + 1 : L_jj is stored and its padded copy sits in the LDS ring slot j mod 4
-// A wave walks the columns at its own pace: chains of its (up to two look-ahead) rows of column j as soon as row j's tiles
-// are final, solves / stores / incremental diagonal updates once L_jj is there; the owner of row j+1 finishes tile
-// (j+1, j) first, so the serial path per column is one solve + one diagonal update + one factorisation.  The ring slot
-// of column j is reused by column j + 4: its owner waits until every wave has left column j (progress words).
-// Same fmaf chains in the same order as the barrier kernel: bit-identical L, alpha.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(512, K3_ASYNC_MINW) void ongpis_chol_async_kernel(const ClusterModel* __restrict__ models, const int* __restrict__ d_jobs,
-                                                                 int* __restrict__ ctl) {
-    constexpr int NW = 8, RING = 4;
-    __shared__ __attribute__((aligned(16))) float D[32 * 33];
-    __shared__ __attribute__((aligned(16))) float Lcs[RING][32 * 32];
-    __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
-    __shared__ float av[32];
-    __shared__ int flags_s[2 + NW];     // f_tiles, f_ready, progress of the 8 waves (columns left behind)
-    typedef volatile int __attribute__((address_space(3))) * lds_flag_ptr;
-    lds_flag_ptr fl = (lds_flag_ptr)flags_s;
-    const int job = blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
-    const int K = m.K, ld = m.ld, nb = m.nb;
-    float* L = m.L;
-    const int nbr = ld / 32;
-    const int ntl = nbr * (nbr + 1) / 2;
-    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
-    const int Tvoff = lane * 16;
-    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
-    const int Lvoff = (l31 + 4 * h * ld) * 4;
-    const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
-    auto tile_soff = [&](int bi, int jc, int r) { return (unsigned)((bi * 32 + (size_t)(jc * 32 + (r & 3) + 8 * (r >> 2)) * ld) * 4); };
-    auto load_tile = [&](float (&o)[16], int b, int c) {
-        const int sbase = tri_index(b, c) * 4096;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + gg * 1024, 0);
-            o[4 * gg + 0] = __uint_as_float(q[0]); o[4 * gg + 1] = __uint_as_float(q[1]);
-            o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
-        }
-    };
-    if (tid < 2 + NW) fl[tid] = 0;
-    __syncthreads();
-    // a wave waits for an LDS counter (bounded by the 100 MHz clock: on expiry bit 1 of the error word, the counters are
-    // poisoned so that the other waves leave as well, and the host drops the batch)
-    auto wait_ge = [&](int idx, int v) -> bool {
-        int cur = fl[idx];
-        if (cur >= v) return true;
-        const long long t0 = wall_clock64();
-        for (;;) {
-            __builtin_amdgcn_s_sleep(2);
-            cur = fl[idx];
-            if (cur >= v) return true;
-            if (cur < 0 || wall_clock64() - t0 > wait_ticks) {
-                if (lane == 0) { atomicOr(ctl, 2); fl[0] = -(1 << 30); fl[1] = -(1 << 30); }
-                return false;
-            }
-        }
-    };
-    auto chain = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
-        if (j > 0) {
-            float a_[2][16], bq[2][16];
-            load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
-#pragma unroll 1
-            for (int p = 0; p < j; p += 2) {
-                if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(bq[1], bi, p + 1); }
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[0][kk], acc, 0, 0, 0);
-                if (p + 1 < j) {
-                    if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(bq[0], bi, p + 2); }
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[1][kk], acc, 0, 0, 0);
-                }
-            }
-        }
-    };
-    // two rows at once: the row-j tile is fetched once per p and the two accumulator chains alternate on the matrix pipe (a
-    // single chain of dependent matrix instructions runs at about half the pipe's rate: cycle stamps, profiles/r03_k3_ablation.txt)
-    auto chain2 = [&](f32x16& acc0, f32x16& acc1, int bi0, int bi1, int j) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            acc0[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi0, j, r), 0));
-            acc1[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi1, j, r), 0));
-        }
-        if (j > 0) {
-            float a_[2][16], b0[2][16], b1[2][16];
-            load_tile(a_[0], j, 0); load_tile(b0[0], bi0, 0); load_tile(b1[0], bi1, 0);
-#pragma unroll 1
-            for (int p = 0; p < j; p += 2) {
-                if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(b0[1], bi0, p + 1); load_tile(b1[1], bi1, p + 1); }
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], b0[0][kk], acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], b1[0][kk], acc1, 0, 0, 0);
-                }
-                if (p + 1 < j) {
-                    if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(b0[0], bi0, p + 2); load_tile(b1[0], bi1, p + 2); }
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) {
-                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], b0[1][kk], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], b1[1][kk], acc1, 0, 0, 0);
-                    }
-                }
-            }
-        }
-    };
-    auto finish = [&](f32x16& acc, int bi, int j, const float* Lc) __attribute__((always_inline)) {
-        diag_solve32<K3_ASYNC_MINW == 2>(acc, Lc, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
-        float* T = Tt[wave];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        float tq[16];      // -L(bi, j) in A-operand order
-        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            float4 q;
-            q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
-            q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
-            q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
-            q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
-            dst[gg * 64 + lane] = q;
-            tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (bi < nb) {     // incremental diagonal of row bi (this wave's own tile, kept in memory: device-scope loads past the L1)
-            f32x16 dacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
-        }
-    };
-    // the LDS counter moves after this wave's memory stores have been acknowledged and its LDS writes are done
-    auto publish = [&](int idx, int v) {
-        __builtin_amdgcn_s_waitcnt(0x0070);                 // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0 && fl[idx] >= 0) fl[idx] = v;
-    };
-
-    bool ok = true;
-    for (int j = 0; j < nb && ok; ++j) {
-        const int pw = min(32, K - 32 * j);
-        const bool owner = (j % NW) == wave;
-        float* Lc = Lcs[j % RING];
-        const int first = j + 1 + ((wave - (j + 1)) % NW + NW) % NW;     // first row > j of this wave
-        const int bi0 = first, bi1 = first + NW;
-        f32x16 acc0, acc1;
-        if (owner) {
-            publish(0, j + 1);                                   // row j's tiles (this wave's own earlier work) are final
-            // the ring slot of column j - RING must have been left by every wave
-            if (j >= RING) for (int x = 0; x < NW && ok; ++x) ok = wait_ge(2 + x, j - RING + 1);
-            if (!ok) break;
-            f32x16 t;      // the accumulated diagonal block: lane = row, 16 of the 32 columns per lane half
-#pragma unroll
-            for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
-            if (pw == 32) {
-                // micro-blocked factorisation in accumulator layout (tile_solve.h: the fused kernel's; same operations in the same
-                // order as factor32_inreg, the trailing updates of a micro-block as four matrix instructions), straight into the ring slot
-                factor32_mb<0>(t, l31, h, lane, Lc);
-                factor32_mb<1>(t, l31, h, lane, Lc);
-                factor32_mb<2>(t, l31, h, lane, Lc);
-                factor32_mb<3>(t, l31, h, lane, Lc);
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 32) {
-#pragma unroll
-                    for (int c = 0; c < 32; ++c)
-                        if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Lc[c * 32 + lane]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) D[l31 * 33 + rowmap_t(r, h)] = t[r];
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
-#pragma unroll 1
-                for (int c = 0; c < pw; ++c) {
-                    float d = sqrtf(Dv[c * 33 + c]);
-                    float lij = 0.f;
-                    const bool below = (lane > c && lane < 32);
-                    if (below) lij = Dv[lane * 33 + c] / d;
-                    if (lane == c) Dv[c * 33 + c] = d;
-                    if (below) Dv[lane * 33 + c] = lij;
-                    if (below) {
-                        const float nl = -lij;
-                        const int kend = min(lane, pw - 1);
-                        for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (lane < 32) {
-#pragma unroll 1
-                    for (int c = 0; c < 32; ++c) {     // (rolled, stores through the buffer resource: 32 hoisted 64-bit addresses are 64 VGPRs)
-                        float v = Dv[lane * 33 + c];
-                        Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
-                        if (c < pw && c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
-                    }
-                }
-            }
-            // (L_jj reaches the other waves through the LDS ring slot: the counter does not wait for the memory stores)
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            if (lane == 0 && fl[1] >= 0) fl[1] = j + 1;
-            // inv(L_jj) -> diagonal slot of Lt (K3b / K4 read it; nobody in this kernel does)
-            f32x16 x;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
-            diag_solve32<K3_ASYNC_MINW == 2>(x, Lc, h);
-            // (through the buffer resource: one VGPR byte offset per lane + scalar offsets -- sixteen 64-bit addresses are hoisted and spilled)
-            const int dvoff = ((((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3)) + 16 * h) * 4;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(x[r]), Trs, dvoff, tri_index(j, j) * 4096 + ((r & 3) + 8 * (r >> 2)) * 16, 0);
-        }
-        if (first < nbr) {
-            if (K3_ASYNC_MINW == 2) {
-                if (!owner) { ok = wait_ge(0, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-                if (bi1 < nbr) chain2(acc0, acc1, bi0, bi1, j);
-                else chain(acc0, bi0, j);
-                if (!owner) { ok = wait_ge(1, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-                finish(acc0, bi0, j, Lc);
-                if (bi1 < nbr) finish(acc1, bi1, j, Lc);
-                for (int bi = bi1 + NW; bi < nbr; bi += NW) {     // (more than two rows per wave: the rest without look-ahead)
-                    f32x16 acc;
-                    chain(acc, bi, j);
-                    finish(acc, bi, j, Lc);
-                }
-            } else {
-                // lean variant (128 VGPRs, two workgroups per CU): one row at a time, ONE instance of chain and finish; the
-                // other workgroup of the CU fills the matrix pipe while this wave solves or waits
-                if (!owner) { ok = wait_ge(0, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-#pragma unroll 1
-                for (int bi = first; bi < nbr; bi += NW) {
-                    chain(acc0, bi, j);
-                    if (bi == first && !owner) { ok = wait_ge(1, j + 1); if (!ok) break; __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
-                    finish(acc0, bi, j, Lc);
-                }
-                if (!ok) break;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                      // (this wave's reads of the ring slot are done)
-        if (lane == 0) fl[2 + wave] = j + 1;
-    }
-    if (lane == 0 && !ok) fl[2 + wave] = 1 << 30;
-    if (lane == 0 && ok) fl[2 + wave] = 1 << 30;                 // (a wave that is through never holds a ring slot)
-    __syncthreads();
-    if (fl[0] < 0) return;                                       // a wait expired: the error word is set, no epilogue
-    chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
-}
+#ifdef GPIS_EXPERIMENTS
+#include "../../tools/experiments/ongpis_chol_async.inc"   // barrier-free one-workgroup factorisation (measured equal on the frames)
+#endif
 
 // ---------------------------------------------------------------------------
 // K3b: explicit inverse X = L^-1 of a trained factor, re-tiled for K4.  grid = (job, block column) pairs,
@@ -1321,20 +1061,22 @@ void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njo
     else hipLaunchKernelGGL((ongpis_chol_kernel<K3_T0_NT, K3_T0_NW>), dim3(njobs), dim3(64 * K3_T0_NW), 0, s, d_models, d_jobs);
 }
 
+#ifdef GPIS_EXPERIMENTS
 void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, int njobs, int* d_ctl, hipStream_t s) {
     if (njobs > 0) hipLaunchKernelGGL(ongpis_chol_async_kernel, dim3(njobs), dim3(512), 0, s, d_models, d_jobs, d_ctl);
 }
+#endif
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
     if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync, d_ctl);
 }
 // workgroups of the cooperative kernel that can be resident at once on the current device (its waits need every workgroup
 // of a cluster running): CUs x occupancy, less a sixteenth as a margin for the kernels of the other size groups
 int ongpis_coop_capacity() {
-    int dev = 0, ncu = 0, per_cu = 0;
+    int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ongpis_chol_coop_kernel, 512, 0) != hipSuccess || per_cu < 1) per_cu = 1;
-    // one workgroup per CU is what the schedule is tuned for (the largest clusters want a CU's matrix pipes to themselves)
+    // one workgroup per CU is what the schedule is tuned for (the largest clusters want a CU's matrix pipes to themselves;
+    // the register budget would admit two)
     return std::max(2, ncu - ncu / 16);
 }
 

@@ -21,11 +21,6 @@ import heapq
 
 
 # ---------------------------------------------------------------------------------- queries ----
-def slab_bounds(n, world, rank):
-    """Contiguous slab [lo, hi) of n queries owned by `rank` (kept for comparison; see cyclic_blocks)."""
-    return (n * rank) // world, (n * (rank + 1)) // world
-
-
 def cyclic_blocks(n, world, rank, block=65536):
     """Block-cyclic cut: list of (lo, hi) query ranges owned by `rank` -- blocks rank, rank + world, ... of
     `block` consecutive queries (the last block may be short)."""
@@ -91,32 +86,6 @@ def gather_blocks(res_local, n, world, rank, dst=0, out=None, block=65536, stagi
     for r, b in bufs.items():
         scatter(b, r)
     return out
-
-
-def gather_slabs(res_local, n, world, rank, dst=0, out=None):
-    """Contiguous-slab variant of gather_blocks (one transfer per rank straight into the destination buffer)."""
-    import torch
-    import torch.distributed as dist
-    if world == 1:
-        return res_local
-    if rank == dst:
-        if out is None:
-            out = torch.empty((n,) + tuple(res_local.shape[1:]), dtype=res_local.dtype, device=res_local.device)
-        lo, hi = slab_bounds(n, world, rank)
-        if out[lo:hi].data_ptr() != res_local.data_ptr():
-            out[lo:hi].copy_(res_local)
-        ops = []
-        for r in range(world):
-            if r == dst:
-                continue
-            lo, hi = slab_bounds(n, world, r)
-            ops.append(dist.P2POp(dist.irecv, out[lo:hi], r))
-        for w in dist.batch_isend_irecv(ops):
-            w.wait()
-        return out
-    for w in dist.batch_isend_irecv([dist.P2POp(dist.isend, res_local, dst)]):
-        w.wait()
-    return None
 
 
 # --------------------------------------------------------------------------------- training ----

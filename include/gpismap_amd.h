@@ -169,18 +169,12 @@ int   gpis_ongpis_set_exp_table(void* s, int on);
  * reference matern32_sparse_deriv1_3D / _2D (train), covFnc.cpp:142-256 / :317-402 */
 int   gpis_ongpis_kernel_matrix(void* s, const float* x, const int* gidx, const float* sigx, const float* sigg, int n, float* K_out);
 int   gpis_ongpis_set_keep_factor(void* s, int on);
-/* opt-in experiment: prediction for clusters of at most 287 rows through a kernel that keeps the inverse factor in registers
- * across the queries of a cluster (same results as the general kernel, bit for bit; measured slower on MI355X, default off) */
-int   gpis_ongpis_set_small_kernel(void* s, int on);
 int   gpis_ongpis_set_fused(void* s, int on);
 /* Lazy inverse (default on): training of clusters of more than 256 rows stops at the factor and alpha (what
  * OnGPIS::train computes, OnGPIS.cpp:139-143); the explicit inverse the prediction kernel multiplies with is computed at the
  * first prediction / packing after a training, once per cluster however often it was retrained in between.  on = 0: the
  * inverse runs behind the factorisation in every training batch. */
 int   gpis_ongpis_set_lazy_inverse(void* s, int on);
-/* opt-in experiment: the one-workgroup factorisation of clusters of more than 256 rows without a barrier per block column
- * (block rows owned by wavefronts, two LDS counters per column; same results bit for bit, 3-6 % faster as a kernel) */
-int   gpis_ongpis_set_async_chol(void* s, int on);
 /* In-kernel waits (the cooperative factorisation of the largest clusters, the pipelined inverse) are bounded: when one
  * expires the batch's models are dropped and training returns GPIS_ERR_STATE.  wait_limit_ms = 0 keeps the default
  * (2 s); inject != 0 is a TEST hook that makes one workgroup of every cooperative cluster withhold a hand-over, so that

@@ -107,11 +107,6 @@ def _gloo_worker(rank, world, port, out):
     n = 1003
     full = torch.arange(n * 8, dtype=torch.float32).reshape(n, 8)
     ok = True
-    # contiguous slabs
-    lo, hi = sharding.slab_bounds(n, world, rank)
-    got = sharding.gather_slabs(full[lo:hi].clone(), n, world, rank, dst=0)
-    if rank == 0:
-        ok = ok and bool(torch.equal(got, full))
     # block-cyclic cut (ragged last block, more blocks than ranks, fewer blocks than ranks)
     for block in (64, 100, 700, 5000):
         mine = sharding.take_blocks(full, world, rank, block).clone()      # stands for this rank's test() output
@@ -121,7 +116,7 @@ def _gloo_worker(rank, world, port, out):
             ok = ok and bool(torch.equal(got, full))
     parts = sharding.shard_clusters([5.0, 1.0, 9.0, 3.0, 3.0, 2.0, 8.0], world)
     ok = ok and sorted(sum(parts, [])) == list(range(7))
-    out.put((rank, ok, (lo, hi)))
+    out.put((rank, ok, sharding.local_count(n, world, rank, 64)))
     dist.destroy_process_group()
 
 
@@ -138,8 +133,7 @@ def test_query_cut_and_gather_gloo(world):
     for p in ps:
         p.join(timeout=60)
     assert all(r[1] for r in res), res
-    if world == 2:
-        assert res[0][2] == (0, 501) and res[1][2] == (501, 1003)
+    assert sum(r[2] for r in res) == 1003
 
 
 def test_block_cyclic_cut_covers_every_query_once_and_balances_z():
@@ -220,5 +214,7 @@ def test_no_kernel_spills_or_uses_scratch():
     assert any("ongpis_train_fused_kernel" in names[k] for k in t) and any("ongpis_eval_kernel" in names[k] for k in t)
     bad = {names[k]: (r["spill"], r["scratch"]) for k, r in t.items() if r["spill"] or r["scratch"]}   # (SGPRs parked in VGPR lanes are not memory traffic)
     assert not bad, bad
+    # the archived experiments (tools/experiments/) are not in the product build
+    assert not [names[k] for k in t if "eval_small" in names[k] or "chol_async" in names[k]]
     # the dominant kernel keeps its occupancy: K4 at most 128 VGPRs (4 wavefronts per SIMD)
     assert all(r["vgpr"] <= 128 for k, r in t.items() if "ongpis_eval_kernel" in names[k])

@@ -29,7 +29,7 @@ def main():
             if name.startswith("block"):
                 x = sharding.take_blocks(grid, world, r)
             else:
-                lo, hi = sharding.slab_bounds(grid.shape[0], world, r); x = grid[lo:hi]
+                n = grid.shape[0]; x = grid[(n * r) // world:(n * (r + 1)) // world]
             xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
             res = torch.zeros((xd.shape[0], 8), dtype=torch.float32, device=dev)
             gm.test_device(xd.data_ptr(), xd.shape[0], res.data_ptr(), torch.cuda.current_stream().cuda_stream)
