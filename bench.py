@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=5, help="synthetic depth frames fused before testing (SURVEY 8d: F = 5)")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
-    ap.add_argument("--update-repeats", type=int, default=3, help="fuse the frame sequence this many times (fresh maps); per-frame update time = minimum over the repeats")
+    ap.add_argument("--update-repeats", type=int, default=3, help="fuse the frame sequence this many times (fresh maps); headline = median of frames 2..F of the MEDIAN repeat (the minimum over the repeats is a side field)")
     ap.add_argument("--train", default="replicated", choices=["replicated", "sharded"], help="multi-rank update(): every rank trains everything, or its K^3-balanced share + all-gather of the models")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: transfers staged through host memory)")
     ap.add_argument("--block", type=int, default=65536, help="queries per block of the block-cyclic cut")
@@ -106,17 +106,22 @@ def main():
     # sequence is fused --update-repeats times into fresh maps and every frame is reported at its MINIMUM over the repeats
     # (`update_repeats`, `update_ms_frames_all`); the last map is the one the test passes run on.
     reps = max(1, args.update_repeats)
-    upd_all, ph_all = [], []
+    upd_all, ph_all, k3_all = [], [], []
     exch_bytes = 0
     exch_ms = []
     gm = None
-    for rep in range(reps):
+    # Two update() accountings, reps fusions each: first with the EAGER inverse (K3b behind K3 inside every
+    # update(): what a caller that tests after every update pays per frame), then the default LAZY inverse (update() stops at
+    # the factor and alpha like OnGPIS::train; the inverse runs once at the first test()).  The last (lazy) map is the one tested.
+    for rep in range(2 * reps):
+        eager = rep < reps
         if gm is not None:
             del gm
         gm = gpismap_amd.GPisMap3()          # default camera 640x480, fx=fy=568, cx=310, cy=224
         assert gm.device() == local_rank
         gm.set_profile(True)                 # hipEvents around the K4 / K3 launches
         gm.set_pipeline(False)               # the default: synchronous update(), as the reference's
+        gm.set_lazy_inverse(not eager)
         if sharded:
             gm.set_shard(rank, world)
         upd_ms, phases, k3 = [], [], []
@@ -139,8 +144,17 @@ def main():
                            clusters=int(s["last_train_jobs"]), maxK=int(s["last_train_maxK"])))
         upd_all.append(upd_ms)
         ph_all.append(phases)
-    upd_ms = [min(u[f] for u in upd_all) for f in range(args.frames)]
-    phases = [[min(p[f][i] for p in ph_all) for i in range(5)] for f in range(args.frames)]
+        k3_all.append(k3)
+    med_tail = lambda a: float(np.median(a[1:] if len(a) > 1 else a))
+
+    def median_repeat(lo, hi):
+        """index of the repeat in [lo, hi) whose median over frames 2..F is the median among the repeats (upper median)"""
+        order = sorted(range(lo, hi), key=lambda r: med_tail(upd_all[r]))
+        return order[len(order) // 2]
+    r_eager, r_lazy = median_repeat(0, reps), median_repeat(reps, 2 * reps)
+    upd_ms, phases, k3 = upd_all[r_lazy], ph_all[r_lazy], k3_all[r_lazy]
+    upd_ms_eager, k3_eager = upd_all[r_eager], k3_all[r_eager]
+    upd_min = [min(u[f] for u in upd_all[reps:]) for f in range(args.frames)]
     # Lazy inverse (the default): update() trained factors and alpha; the explicit inverses of the clusters retrained since the
     # last prediction are computed by the first test() -- timed here on its own and reported (`deferred_inverse_ms`), so that
     # the timed passes below start from the same state as with the eager inverse.
@@ -327,6 +341,37 @@ def main():
                                   "map_points": om.num_points(), "map_points_gpu": gm.num_points(),
                                   "map_point_count_difference": int(om.num_points() - gm.num_points()),
                                   "branch_ambiguous_in_sample": int(amb.sum())}
+        # (a') the NOISE FLOOR of that figure: two more independent CPU orders, each building its OWN map
+        # over the same frames, compared with each other and with the GPU on the 24^3 sub-sample.  If X<->Y is not below 1e-5,
+        # no fp32 implementation can meet 1e-5 end to end; what is asserted (tests/test_gpu_golden.py) is GPU<->X <= 1.25 max(X<->Y).
+        i3 = np.linspace(0, m - 1, 24).round().astype(np.int64)
+        pk3 = ((i3[:, None, None] * m + i3[None, :, None]) * m + i3[None, None, :]).reshape(-1)
+        own = {"natural": ro[pk3]}
+        amb_f = amb[pk3]
+        for mode in ("fp64acc", "eigen33"):
+            oracle_lib.set_arith_mode(mode)
+            o2 = oracle_lib.OracleMap3()
+            for f in range(args.frames):
+                o2.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+            own[mode] = o2.test(sub[pk3])
+            own[mode + "_points"] = o2.num_points()
+            o2.close()
+        oracle_lib.set_arith_mode("tiled")
+        rms = lambda a, b: [float(np.sqrt(np.mean((a[~amb_f, 0].astype(np.float64) - b[~amb_f, 0]) ** 2))), float(np.sqrt(np.mean((a[:, 0].astype(np.float64) - b[:, 0]) ** 2)))]
+        fl_ = {"floor_natural_vs_fp64acc": rms(own["natural"], own["fp64acc"]), "floor_natural_vs_eigen33": rms(own["natural"], own["eigen33"]),
+               "floor_fp64acc_vs_eigen33": rms(own["fp64acc"], own["eigen33"]),
+               "gpu_vs_natural": rms(rg[pk3], own["natural"]), "gpu_vs_fp64acc": rms(rg[pk3], own["fp64acc"]), "gpu_vs_eigen33": rms(rg[pk3], own["eigen33"]),
+               "map_points": {"gpu": gm.num_points(), "natural": om.num_points(), "fp64acc": own["fp64acc_points"], "eigen33": own["eigen33_points"]},
+               "sample": "24^3 sub-sample (%d queries, %d branch-ambiguous); pairs are SDF RMSE [unmasked, all], every order on its OWN map" % (pk3.size, int(amb_f.sum()))}
+        fl_["max_floor_unmasked"] = max(fl_[k][0] for k in ("floor_natural_vs_fp64acc", "floor_natural_vs_eigen33", "floor_fp64acc_vs_eigen33"))
+        fl_["max_gpu_unmasked"] = max(fl_[k][0] for k in ("gpu_vs_natural", "gpu_vs_fp64acc", "gpu_vs_eigen33"))
+        fl_["gpu_within_1p25_of_floor"] = bool(fl_["max_gpu_unmasked"] <= 1.25 * fl_["max_floor_unmasked"])
+        cpu["own_map_natural"].update({"floor_natural_vs_fp64acc": fl_["floor_natural_vs_fp64acc"][0], "floor_natural_vs_eigen33": fl_["floor_natural_vs_eigen33"][0]})
+        cpu["own_map_noise_floor"] = fl_
+        import eigen_probe
+        einc, ever = eigen_probe.find_eigen()
+        cpu["eigen_on_box"] = bool(einc)
+        cpu["eigen_note"] = ("real Eigen %s at %s: run tests/test_eigen_probe.py" % (ever, einc)) if einc else ("no real Eigen on this box (%s): the eigen33 order stays a restatement from memory, parity unpinned" % ever)
         # (b) the tiled-order oracle holds the GPU's map exactly: bit-exactness on a 16^3 sub-sample, then the ARITHMETIC
         # comparison: every cluster of that same map re-factorised in the natural order (and the Eigen-3.3 order) on its
         # stored training set, test() on a 24^3 sub-sample
@@ -340,8 +385,6 @@ def main():
         cpu["identical_rows_vs_oracle"] = float(np.mean(np.all(rg[pick] == rt, axis=1)))
         cpu["map_points_oracle"] = ot.num_points()
         cpu["map_nodes_identical_to_gpu"] = bool(np.array_equal(ot.nodes(), gm.nodes()))
-        i3 = np.linspace(0, m - 1, 24).round().astype(np.int64)
-        pk3 = ((i3[:, None, None] * m + i3[None, :, None]) * m + i3[None, None, :]).reshape(-1)
         fl3 = ot.test_flags(sub[pk3]); amb3 = (fl3 & 6) != 0
         for mode in ("natural", "eigen33"):
             ot.retrain_all(mode)
@@ -367,11 +410,14 @@ def main():
             if (tj.get("ongpis_test_sha") == file_sha(os.path.join(ROOT, "gpismap_amd", "csrc", "ongpis_test.hip"))
                     and tj.get("grid") == args.grid and tj.get("frames") == args.frames):
                 traffic = tj.get("hbm_bytes_per_launch")
-        med = lambda a: float(np.median(a[1:] if len(a) > 1 else a))
+        med = med_tail
         ph = np.array(phases)
         ksel = k3[1:] if len(k3) > 1 else k3
         k3_ms = float(np.median([k["ms"] for k in ksel]))
         k3_fl = float(np.median([k["flops"] for k in ksel]))
+        ksel_e = k3_eager[1:] if len(k3_eager) > 1 else k3_eager
+        k3e_ms = float(np.median([k["ms"] for k in ksel_e]))
+        k3e_fl = float(np.median([k["flops"] for k in ksel_e]))
         out = {
             "metric": "sdf_test_points_per_sec",
             "value": value,
@@ -392,10 +438,14 @@ def main():
                        "parallelism": ("%s training, query blocks of %d dealt round-robin to %d ranks, RCCL point-to-point gather"
                                        % (args.train, args.block, world)) if world > 1 else "single GPU"},
             "update_ms_per_frame": med(upd_ms),
-            "update_mode": "synchronous (default, as the reference): median of frames 2..F, every frame at its minimum over update_repeats fusions of the sequence",
+            "update_mode": "synchronous update(), default lazy inverse (update() stops at the factor and alpha, as OnGPIS::train does): median of frames 2..F of the MEDIAN repeat of update_repeats fusions of the sequence",
+            "update_ms_per_frame_with_inverse": med(upd_ms_eager),
+            "update_with_inverse_mode": "the same with the eager inverse (gpis3_set_lazy_inverse(map, 0) / GPIS_EAGER_INVERSE=1: K3b inside every update()) -- what a test-after-every-update caller pays per frame; median repeat",
+            "update_ms_per_frame_min_over_repeats": med(upd_min),
             "update_ms_frames": upd_ms,
+            "update_ms_frames_with_inverse": upd_ms_eager,
             "update_repeats": reps,
-            "update_ms_frames_all": upd_all,
+            "update_ms_frames_all": {"eager_inverse": upd_all[:reps], "lazy_inverse": upd_all[reps:]},
             "update_ms_per_frame_pipelined": upd_pipe_mean,
             "update_pipelined": {"note": "opt-in (gpis3_set_pipeline / GPIS_PIPELINE_UPDATE=1): mean of frames 2..F with the drain of the last frame's training charged",
                                  "ms_frames": upd_pipe, "drain_ms": drain_ms},
@@ -410,6 +460,8 @@ def main():
             "per_rank": dict({"gp_evals": [p[0] for p in per_rank], "k4_ms_per_step": [p[1] for p in per_rank]}, **(detail or {})),
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": (tflops / 157.3) if tflops else None, "traffic": traffic,
+                         # HBM-side bytes per launch over the algorithmic bytes per launch (44 B per query + 32 B per evaluated (query, cluster) pair + the models once)
+                         "traffic_ratio": (traffic / ((44.0 * n_loc + 32.0 * evals / max(1, args.steps) + st0["model_bytes"]) / max(1.0, launches / args.steps))) if traffic else None,
                          "kernel": "ongpis_eval_kernel (K4)", "k4_ms_per_step": k4_ms / args.steps,
                          "k4_launches_per_step": launches / args.steps,
                          "algorithmic_flops_per_step": flops / args.steps,
@@ -417,6 +469,8 @@ def main():
             "update_roofline": {"kernel": "K6 gather + kernel build + K3 Cholesky (K3b inverse: deferred to the first test(), see deferred_inverse)", "bound": "mfma",
                                 "ms_per_frame": k3_ms, "algorithmic_flops_per_frame": k3_fl,
                                 "achieved": (k3_fl / 1e12) / (k3_ms / 1e3) if k3_ms > 0 else None, "peak": 157.3, "unit": "TFLOP/s",
+                                "with_inverse": {"ms_per_frame": k3e_ms, "achieved": (k3e_fl / 1e12) / (k3e_ms / 1e3) if k3e_ms > 0 else None,
+                                                 "note": "eager mode: K6 + build + K3 + K3b per frame; same flop count (the inverse's K^3/3 is NOT counted)"},
                                 "clusters": ksel[-1]["clusters"], "max_K": max(k["maxK"] for k in ksel),
                                 "note": "flops = sum K^3/3 + 2 K^2 over the clusters retrained per frame (SURVEY 8d); the explicit inverse (another K^3/3, never counted) runs once at the first test() after the updates: deferred_inverse"},
             "exchange_bytes_per_frame": (exch_bytes / max(1, args.frames)) if sharded else 0,
