@@ -198,8 +198,6 @@ void ongpis_launch_range_gather(const int* d_desc, const int* d_cranges, const i
 void ongpis_launch_chol(const ClusterModel* d_models, const int* d_jobs, int njobs, int tier, hipStream_t s);
 #ifdef GPIS_EXPERIMENTS   // tools/experiments/: archived kernels, built only with EXTRA=-DGPIS_EXPERIMENTS, selected by GPIS_ASYNC_CHOL / GPIS_SMALL_KERNEL
 void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, int njobs, int* d_ctl, hipStream_t s);
-size_t ongpis_eval_small_lds(int maxN, int maxLd);
-int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
 #endif
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup (job < 0: padding), sync = 3 ints per job (zeroed)
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
@@ -240,6 +238,10 @@ struct EvalArgs {
 __host__ __device__ inline int ongpis_class_of_nbx(int nbx) {
     return nbx <= 4 ? 0 : (nbx <= 8 ? 1 : (nbx <= ONGPIS_SMALL_NBX ? 2 : (nbx <= 16 ? 3 : (nbx <= 32 ? 4 : (nbx <= 48 ? 5 : 6)))));
 }
+#ifdef GPIS_EXPERIMENTS
+size_t ongpis_eval_small_lds(int maxN, int maxLd);
+int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);
+#endif
 int ongpis_eval_class(int nbx);
 bool ongpis_eval_fits(int N, int ld);
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s);

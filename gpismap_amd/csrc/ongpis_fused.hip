@@ -35,6 +35,7 @@
 // Then: the eight diagonal blocks are inverted in parallel, four wavefronts run two block columns of X each (transposed
 // tiles kept in registers as the B operands of the later rows), the other four run the back substitution for alpha as
 // a pipeline over row blocks and write the mean rows of Xt.
+#include <cstdlib>
 #include <type_traits>
 #include "ongpis.h"
 #include "tile_solve.h"
@@ -97,33 +98,19 @@ __device__ __forceinline__ void wg_sync() {
 #else
 #define FSTAMP(i) do {} while (0)
 #define FSTAMP_AT(i) do {} while (0)
+#define FSTAMP_W(i) do {} while (0)
 #endif
 
 }  // namespace
 
 size_t ongpis_fused_lds_bytes(int nb) {
-    return sizeof(float) * ((size_t)nb * (nb + 1) / 2 * 1024 + 256 + 256 + kRegion) + 64;   // + the two progress words
+    return sizeof(float) * ((size_t)nb * (nb + 1) / 2 * 1024 + 256 + 256 + kRegion) + 256;   // + the flag words
 }
 
-// NT = largest number of block rows, ZR = transposed X tiles a column of the inverse keeps in registers (NT - 1)
-template <int NT, int ZR, int MINW>
-__global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrainArgs A) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel* __restrict__ mp = A.models + A.jobs[4 * job];
-    const int N = mp->N, ng = mp->ng, K = mp->K, ld = mp->ld, nb = mp->nb, dim = mp->dim;
-    const int ntl = nb * (nb + 1) / 2;
-    if (nb > ZR + 1 || nb > NT || N > 256) {   // host routing error: refuse loudly, touch nothing
-        if (tid == 0) atomicOr(A.err, 1);
-        return;
-    }
-    FSTAMP(0);
-    float* slots = smem;                        // [ntl][1024]: K tiles, then L tiles (A-operand order); diagonal slots: see below
-    float* yv = slots + (size_t)ntl * 1024;     // [256] y -> z -> alpha
-    float* Ldiag = yv + 256;                    // [256] diagonal of L
-    float* R = Ldiag + 256;                     // phase-local region
+// K6 gather + kernel matrix into the LDS tile slots (accumulator order, d_addr), the targets into yv; x4 / rowinfo (/ gidx) of
+// the model are written to global memory.  Shared by the two fused kernels; ends WITHOUT the closing barrier.
+__device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, const ClusterModel* __restrict__ mp, float* slots, float* yv, float* R,
+                                                   int job, int tid, int lane, int wave, int N, int ng, int K, int ld, int nb, int dim, int ntl) {
     // ---------------------------------------------------------------- gather (K6)
     float4* x4s = reinterpret_cast<float4*>(R);              // [N]
     float* sig = R + 1024;                                   // [2 N] sigx' (after the 2.0 override), sigg
@@ -236,6 +223,35 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
             }
         }
     }
+}
+
+#ifndef V1_PRIO_DIAG
+#define V1_PRIO_DIAG 0     // issue priority of the wavefront factorising the diagonal tile (the serial chain of a block column)
+#endif
+#ifndef V1_PRIO_ALPHA
+#define V1_PRIO_ALPHA 3    // ... and of the four wavefronts of the back substitution: they share their SIMDs with the X wavefronts and
+                           // are the tail of the kernel (stress config 24.1 -> 23.1 ms; the diagonal wavefront's priority: no effect)
+#endif
+// NT = largest number of block rows, ZR = transposed X tiles a column of the inverse keeps in registers (NT - 1)
+template <int NT, int ZR, int MINW>
+__global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrainArgs A) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int job = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const ClusterModel* __restrict__ mp = A.models + A.jobs[4 * job];
+    const int N = mp->N, ng = mp->ng, K = mp->K, ld = mp->ld, nb = mp->nb, dim = mp->dim;
+    const int ntl = nb * (nb + 1) / 2;
+    if (nb > ZR + 1 || nb > NT || N > 256) {   // host routing error: refuse loudly, touch nothing
+        if (tid == 0) atomicOr(A.err, 1);
+        return;
+    }
+    FSTAMP(0);
+    float* slots = smem;                        // [ntl][1024]: K tiles, then L tiles (A-operand order); diagonal slots: see below
+    float* yv = slots + (size_t)ntl * 1024;     // [256] y -> z -> alpha
+    float* Ldiag = yv + 256;                    // [256] diagonal of L
+    float* R = Ldiag + 256;                     // phase-local region
+    fused_gather_build(A, mp, slots, yv, R, job, tid, lane, wave, N, ng, K, ld, nb, dim, ntl);
     __syncthreads();
     FSTAMP(2);
 
@@ -290,6 +306,7 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
         // ---- P1.  Two roles, separate instruction streams, four workgroup barriers each: stage q of the owner factorises
         // columns 8q .. 8q+7 of the diagonal tile while the others solve their panel tile against columns 8(q-1) ..
         if (wave == dw) {
+            if (V1_PRIO_DIAG) __builtin_amdgcn_s_setprio(V1_PRIO_DIAG);
             f32x16 t;
             {
                 const float4* tt = reinterpret_cast<const float4*>(Lc);
@@ -308,6 +325,7 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
             factor32_mb<2>(t, l31, h, lane, Lc);
             wg_sync();
             factor32_mb<3>(t, l31, h, lane, Lc);
+            if (V1_PRIO_DIAG) __builtin_amdgcn_s_setprio(0);
             wg_sync();
             if (lane < 32) Ldiag[32 * j + lane] = Lc[lane * 32 + lane];
         } else {
@@ -502,6 +520,7 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
         }
         FSTAMP(29);
     } else {
+        if (V1_PRIO_ALPHA) __builtin_amdgcn_s_setprio(V1_PRIO_ALPHA);
         // ------------------------------------------------------------ alpha = L^-T z, blocked, descending chains (O2).
         // Row block r belongs to wavefront 4 + (r & 3): it folds the blocks below into its rows as they are published
         // (aflag = blocks done, from the last one up), then solves its own 32 x 32 triangle and publishes.  The chain of
@@ -596,12 +615,20 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
     }
 }
 
+
+#ifdef GPIS_EXPERIMENTS
+#include "../../tools/experiments/ongpis_fused_df.inc"   // data-flow schedule of the same factorisation (measured slower)
+#endif
+
 int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hipStream_t s) {
     if (njobs <= 0) return GPIS_OK;
     if (max_nb < 1 || max_nb > 8) return GPIS_ERR_ARG;
     typedef void (*kern_t)(FusedTrainArgs);
     const bool small = max_nb <= 5;   // 15 tiles: two accumulator tiles per wavefront, two workgroups per CU
-    const kern_t kern = small ? (kern_t)ongpis_train_fused_kernel<5, 4, 3> : (kern_t)ongpis_train_fused_kernel<8, 7, 2>;
+    kern_t kern = small ? (kern_t)ongpis_train_fused_kernel<5, 4, 3> : (kern_t)ongpis_train_fused_kernel<8, 7, 2>;
+#ifdef GPIS_EXPERIMENTS
+    if (!small && getenv("GPIS_FUSED_DF") && atoi(getenv("GPIS_FUSED_DF"))) kern = (kern_t)ongpis_train_fused_df_kernel<2>;
+#endif
     const size_t lds = ongpis_fused_lds_bytes(max_nb);
     if (ensure_dynamic_lds((const void*)kern, 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
     hipLaunchKernelGGL(kern, dim3(njobs), dim3(kFT), lds, s, a);
