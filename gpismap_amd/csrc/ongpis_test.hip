@@ -70,7 +70,11 @@ typedef const int __attribute__((address_space(1))) * giptr;
                             // waves generating (6 x 4 rows per group) 1497 ms/step, unified 1360 ms/step
 #endif
 
-constexpr int kTileStride = 36;                 // floats per row of a B tile in LDS (conflict-free 16-byte row writes AND operand reads)
+#ifndef K4_BT
+#define K4_BT 1             // B tiles in LDS k-contiguous per column: Bt[n][h][kk] = B[2 kk + h][n], so that the 16 operand values of a lane are
+                            // FOUR 16-byte reads instead of sixteen 4-byte reads (the operand reads of 16 wavefronts took half of the LDS cycles)
+#endif
+constexpr int kTileStride = 36;                 // floats per row (K4_BT: per column) of a B tile in LDS: conflict-free writes AND operand reads
 constexpr int kTileFloats = 32 * kTileStride;   // 1152
 
 // W wavefronts of which WP only generate B tiles (0: every wavefront generates and multiplies), NBW block rows per
@@ -184,7 +188,14 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                 if (dim == 2) v3 = 0.f;
                 o = make_float4(v0, v1, v2, v3);
             }
-            trow[j] = o;
+            if (K4_BT) {
+                // element (row, n = 16 qh + 4 j + comp) -> tbuf[n * 36 + (row & 1) * 16 + (row >> 1)]: the 32 rows of a wavefront's
+                // store instruction fall into 32 different banks
+                float* tcol = tbuf + (16 * qh + 4 * j) * kTileStride + (rr_ & 1) * 16 + (rr_ >> 1);
+                tcol[0] = o.x; tcol[kTileStride] = o.y; tcol[2 * kTileStride] = o.z; tcol[3 * kTileStride] = o.w;
+            } else {
+                trow[j] = o;
+            }
         }
     };
     auto gen_tile = [&](int c, int qs, float* tbuf) {
@@ -232,6 +243,24 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     // independent accumulator chains of the sets interleaved
     const bool two = (QS == 2) && (nset == 2);
     auto mfma_tile = [&](f32x16& acc0, f32x16& acc1, const float (&av)[16], const float* Bt) {
+        if (K4_BT) {
+            const float4* Bq = reinterpret_cast<const float4*>(Bt + l31 * kTileStride + h * 16);
+            float bv[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) { const float4 q = Bq[g]; bv[4 * g] = q.x; bv[4 * g + 1] = q.y; bv[4 * g + 2] = q.z; bv[4 * g + 3] = q.w; }
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc0, 0, 0, 0);
+            if (QS == 2) {
+                if (two) {
+                    const float4* Bq1 = reinterpret_cast<const float4*>(Bt + kTileFloats + l31 * kTileStride + h * 16);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) { const float4 q = Bq1[g]; bv[4 * g] = q.x; bv[4 * g + 1] = q.y; bv[4 * g + 2] = q.z; bv[4 * g + 3] = q.w; }
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk], bv[kk], acc1, 0, 0, 0);
+                }
+            }
+            return;
+        }
         const float* Bl = Bt + h * kTileStride + l31;
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
@@ -311,13 +340,16 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 #pragma unroll 1
                             for (int c = c0; c <= cend; ++c) {
                                 const float* Bl = buf + (size_t)(c - c0) * QS * kTileFloats + h * kTileStride + l31;
+                                const float4* Bq = reinterpret_cast<const float4*>(buf + (size_t)(c - c0) * QS * kTileFloats + l31 * kTileStride + h * 16);
                                 const int cn = min(c + 1, cend);
                                 const int nbase = (b * (b + 1) / 2 + cn) * 4096;
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
+                                    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    if (K4_BT) bq = Bq[g];
 #pragma unroll
                                     for (int j = 0; j < 4; ++j)
-                                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[4 * g + j], Bl[(4 * g + j) * 2 * kTileStride], acc[t][0], 0, 0, 0);
+                                        acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[4 * g + j], K4_BT ? (j == 0 ? bq.x : (j == 1 ? bq.y : (j == 2 ? bq.z : bq.w))) : Bl[(4 * g + j) * 2 * kTileStride], acc[t][0], 0, 0, 0);
                                     auto q = __builtin_amdgcn_raw_buffer_load_b128(Xrs, Tvoff, nbase + g * 1024, 0);
                                     av1[4 * g + 0] = __uint_as_float(q[0]); av1[4 * g + 1] = __uint_as_float(q[1]);
                                     av1[4 * g + 2] = __uint_as_float(q[2]); av1[4 * g + 3] = __uint_as_float(q[3]);
@@ -419,6 +451,9 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     const size_t share = std::min(hard, hard * W / kWavesPerCU);
     const size_t blk = kQS * sizeof(float) * kTileFloats;    // one column block, all query sets
     int use_table = args_in.use_table ? 1 : 0;
+#ifdef K4_NO_TABLE
+    use_table = 0;
+#endif
     size_t fixed = eval_lds_fixed(W, maxN, maxLd, use_table);
     if (use_table && fixed + 4 * blk > share) {              // the exp table does not fit beside a useful ring
         const size_t f0 = eval_lds_fixed(W, maxN, maxLd, 0);
@@ -463,6 +498,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
 }
 
 int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }
+
 
 // Can K4 hold a cluster of N points / leading dimension ld?  It stages the row table and the points in LDS beside a
 // two-slot ring of at least one column block each (the exp table is optional).  Asked at TRAINING time: a cluster that
