@@ -425,6 +425,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     K4_STAMP();
 }
 
+
+#ifdef GPIS_EXPERIMENTS
+#include "../../tools/experiments/ongpis_eval_seg.inc"   // several consecutive tiles per workgroup, pipelined across the tiles (measured no faster)
+#endif
+
 // Size classes by nbx = ceil((K+1)/32): W wavefronts per workgroup (ongpis.h, ongpis_class_of_nbx).
 static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, 4, K4_W3, K4_W3, K4_W3};
 constexpr int kQS = ONGPIS_TILE_Q / 8;
@@ -480,6 +485,23 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
         {ongpis_eval_kernel<1, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, true, kQS, K4_NBW, 0>,
          ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW, K4_WP3>}};
     const int kidx = wclass < 3 ? wclass : (wclass == 3 ? 2 : 3);
+#ifdef GPIS_EXPERIMENTS
+    // several consecutive tiles per workgroup, software-pipelined across the tiles (K4_SEG tiles; 0: one tile per workgroup, the kernel above)
+    static const int seg_env = getenv("GPIS_K4_SEG") ? atoi(getenv("GPIS_K4_SEG")) : 0;
+    if (seg_env > 0 && kQS == 1) {
+        typedef void (*skern_t)(EvalArgs, int, int);
+        static const skern_t skern[2][4] = {
+            {ongpis_eval_seg_kernel<1, false, K4_NBW>, ongpis_eval_seg_kernel<2, false, K4_NBW>, ongpis_eval_seg_kernel<4, false, K4_NBW>, ongpis_eval_seg_kernel<K4_W3, false, K4_NBW>},
+            {ongpis_eval_seg_kernel<1, true, K4_NBW>, ongpis_eval_seg_kernel<2, true, K4_NBW>, ongpis_eval_seg_kernel<4, true, K4_NBW>, ongpis_eval_seg_kernel<K4_W3, true, K4_NBW>}};
+        if (ensure_dynamic_lds((const void*)skern[use_table][kidx], 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
+        args.nslot = 2;
+        const size_t lds2 = fixed + (size_t)2 * cb * blk;
+        hipLaunchKernelGGL(skern[use_table][kidx], dim3((ntiles + seg_env - 1) / seg_env), dim3(64 * W), lds2, s, args, ntiles, seg_env);
+        const hipError_t le2 = hipGetLastError();
+        if (le2 != hipSuccess) { fprintf(stderr, "[gpismap_amd] K4 launch failed: %s (class %d, %d waves, %d tiles, segment %d)\n", hipGetErrorString(le2), wclass, W, ntiles, seg_env); return GPIS_ERR_HIP; }
+        return GPIS_OK;
+    }
+#endif
     if (ensure_dynamic_lds((const void*)kern[use_table][kidx], 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
 #ifdef GPIS_INSTRUMENT
     k4_trace_arm(args, s);
