@@ -107,7 +107,7 @@ def main():
     # (`update_repeats`, `update_ms_frames_all`); the last map is the one the test passes run on.
     reps = max(1, args.update_repeats)
     upd_all, ph_all, k3_all = [], [], []
-    exch_bytes = 0
+    exch_bytes = exch_padded = exch_records = 0
     exch_ms = []
     gm = None
     # Two update() accountings, reps fusions each: first with the EAGER inverse (K3b behind K3 inside every
@@ -125,7 +125,7 @@ def main():
         if sharded:
             gm.set_shard(rank, world)
         upd_ms, phases, k3 = [], [], []
-        exch_bytes = 0
+        exch_bytes = exch_padded = exch_records = 0
         for f in range(args.frames):
             depth = replay.synthetic_depth(f)
             if world > 1:
@@ -134,8 +134,8 @@ def main():
             gm.update(depth, replay.IDENTITY_POSE)
             if sharded:
                 te = time.perf_counter()
-                _, nb = sharding.exchange_models(gm, world, rank, dev, host_staged)
-                exch_bytes += nb
+                _, nb, npad, nrec = sharding.exchange_models(gm, world, rank, dev, host_staged)
+                exch_bytes += nb; exch_padded += npad; exch_records += nrec
                 exch_ms.append((time.perf_counter() - te) * 1e3)
             upd_ms.append((time.perf_counter() - t0) * 1e3)
             s = gm.stats()
@@ -473,7 +473,11 @@ def main():
                                                  "note": "eager mode: K6 + build + K3 + K3b per frame; same flop count (the inverse's K^3/3 is NOT counted)"},
                                 "clusters": ksel[-1]["clusters"], "max_K": max(k["maxK"] for k in ksel),
                                 "note": "flops = sum K^3/3 + 2 K^2 over the clusters retrained per frame (SURVEY 8d); the explicit inverse (another K^3/3, never counted) runs once at the first test() after the updates: deferred_inverse"},
+            # sharded training: bytes of model records rank 0 receives per frame (records at their own sizes, back to back), what the
+            # one all_gather_into_tensor delivers (slots padded to the largest RANK total), and the sum of all records of a frame
             "exchange_bytes_per_frame": (exch_bytes / max(1, args.frames)) if sharded else 0,
+            "exchange_bytes_per_frame_delivered": (exch_padded / max(1, args.frames)) if sharded else 0,
+            "exchange_record_bytes_per_frame": (exch_records / max(1, args.frames)) if sharded else 0,
             "value_host_api": host_api,
             "stress": stress,
             "cpu_baseline": cpu,

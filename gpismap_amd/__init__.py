@@ -46,9 +46,9 @@ def lib():
     L.gpis3_device.argtypes = [vp]
     L.gpis3_set_shard.argtypes = [vp, C.c_int, C.c_int]
     L.gpis3_shard_info.argtypes = [vp, ip, C.c_int]
-    L.gpis3_shard_packed_bytes.argtypes = [vp]; L.gpis3_shard_packed_bytes.restype = C.c_longlong
-    L.gpis3_shard_pack.argtypes = [vp, vp, C.c_longlong, vp]
-    L.gpis3_shard_unpack.argtypes = [vp, C.c_int, vp, C.c_int, C.c_longlong, vp]
+    L.gpis3_shard_bytes.argtypes = [vp, C.c_int]; L.gpis3_shard_bytes.restype = C.c_longlong
+    L.gpis3_shard_pack.argtypes = [vp, vp, vp]
+    L.gpis3_shard_unpack.argtypes = [vp, C.c_int, vp, vp]
     L.gpis3_shard_finish.argtypes = [vp]
     L.gpis_ongpis_packed_bytes.argtypes = [vp, ip, C.c_int]; L.gpis_ongpis_packed_bytes.restype = C.c_longlong
     L.gpis_ongpis_pack.argtypes = [vp, ip, C.c_int, vp, C.c_longlong, vp]
@@ -138,7 +138,7 @@ class GPisMap3:
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
                  "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK",
-                 "last_inverse_ms", "last_inverse_jobs")
+                 "last_inverse_ms", "last_inverse_jobs", "exchange_bytes")
 
     def __init__(self, cam6=None, devices=None):
         """devices: list of HIP device ids for ONE map over several devices (gpis3_create_multi; a device may repeat:
@@ -208,15 +208,19 @@ class GPisMap3:
         _check(self.L.gpis3_shard_info(self.h, _p(out, C.c_int), 2 + w), "gpis3_shard_info")
         return int(out[0]), int(out[1]), [int(v) for v in out[2:]]
 
-    def shard_packed_bytes(self):
-        return int(self.L.gpis3_shard_packed_bytes(self.h))
+    def shard_bytes(self, owner):
+        """Bytes of rank `owner`'s packed records of the last update (records back to back at their own sizes; every rank
+        gives the same answer for every owner)."""
+        b = int(self.L.gpis3_shard_bytes(self.h, int(owner)))
+        if b < 0:
+            raise GpisError("gpis3_shard_bytes failed (%d)" % b)
+        return b
 
-    def shard_pack(self, d_buf_ptr, stride, stream=0):
-        _check(self.L.gpis3_shard_pack(self.h, C.c_void_p(d_buf_ptr), int(stride), C.c_void_p(stream)), "gpis3_shard_pack")
+    def shard_pack(self, d_buf_ptr, stream=0):
+        _check(self.L.gpis3_shard_pack(self.h, C.c_void_p(d_buf_ptr), C.c_void_p(stream)), "gpis3_shard_pack")
 
-    def shard_unpack(self, owner, d_buf_ptr, n, stride, stream=0):
-        _check(self.L.gpis3_shard_unpack(self.h, int(owner), C.c_void_p(d_buf_ptr), int(n), int(stride), C.c_void_p(stream)),
-               "gpis3_shard_unpack")
+    def shard_unpack(self, owner, d_buf_ptr, stream=0):
+        _check(self.L.gpis3_shard_unpack(self.h, int(owner), C.c_void_p(d_buf_ptr), C.c_void_p(stream)), "gpis3_shard_unpack")
 
     def shard_finish(self):
         _check(self.L.gpis3_shard_finish(self.h), "gpis3_shard_finish")
@@ -239,8 +243,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 23)()
-        _check(self.L.gpis3_stats(self.h, a, 23), "gpis3_stats")
+        a = (C.c_double * 24)()
+        _check(self.L.gpis3_stats(self.h, a, 24), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def set_profile(self, on=True):

@@ -29,9 +29,9 @@ int gpis3_impl_num_devices(GPisMap3* m);
 GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, const int* devices, int n);
 int gpis3_impl_set_shard(GPisMap3* m, int rank, int world);
 int gpis3_impl_shard_info(GPisMap3* m, int* out, int n);
-long long gpis3_impl_shard_packed_bytes(GPisMap3* m);
-int gpis3_impl_shard_pack(GPisMap3* m, void* d_buf, long long stride, void* stream);
-int gpis3_impl_shard_unpack(GPisMap3* m, int owner, const void* d_buf, int n, long long stride, void* stream);
+long long gpis3_impl_shard_bytes(GPisMap3* m, int owner);
+int gpis3_impl_shard_pack(GPisMap3* m, void* d_buf, void* stream);
+int gpis3_impl_shard_unpack(GPisMap3* m, int owner, const void* d_buf, void* stream);
 int gpis3_impl_shard_finish(GPisMap3* m);
 int gpis2_impl_device(GPisMap* m);
 
@@ -107,14 +107,14 @@ int gpis3_set_shard(void* m, int rank, int world) {
     return gpis3_impl_set_shard((GPisMap3*)m, rank, world);
 }
 int gpis3_shard_info(void* m, int* out, int n) { if (!m || !out) return GPIS_ERR_ARG; return gpis3_impl_shard_info((GPisMap3*)m, out, n); }
-long long gpis3_shard_packed_bytes(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_packed_bytes((GPisMap3*)m); }
-int gpis3_shard_pack(void* m, void* d_buf, long long stride, void* stream) {
-    if (!m || stride < 256 || stride % 256 != 0) return GPIS_ERR_ARG;
-    return gpis3_impl_shard_pack((GPisMap3*)m, d_buf, stride, stream);
+long long gpis3_shard_bytes(void* m, int owner) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_bytes((GPisMap3*)m, owner); }
+int gpis3_shard_pack(void* m, void* d_buf, void* stream) {
+    if (!m) return GPIS_ERR_ARG;
+    return gpis3_impl_shard_pack((GPisMap3*)m, d_buf, stream);
 }
-int gpis3_shard_unpack(void* m, int owner, const void* d_buf, int n, long long stride, void* stream) {
-    if (!m || stride < 256 || stride % 256 != 0 || n < 0) return GPIS_ERR_ARG;
-    return gpis3_impl_shard_unpack((GPisMap3*)m, owner, d_buf, n, stride, stream);
+int gpis3_shard_unpack(void* m, int owner, const void* d_buf, void* stream) {
+    if (!m) return GPIS_ERR_ARG;
+    return gpis3_impl_shard_unpack((GPisMap3*)m, owner, d_buf, stream);
 }
 int gpis3_shard_finish(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_finish((GPisMap3*)m); }
 int gpis3_num_points(void* m) {

@@ -26,9 +26,9 @@
 // (defined at the end of this file; used by the several-devices paths above them)
 GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, const int* devices, int n);
 int gpis3_impl_shard_info(GPisMap3* g, int* out, int n);
-long long gpis3_impl_shard_packed_bytes(GPisMap3* g);
-int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, long long stride, void* stream);
-int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, int n, long long stride, void* stream);
+long long gpis3_impl_shard_bytes(GPisMap3* g, int owner);
+int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, void* stream);
+int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, void* stream);
 int gpis3_impl_shard_finish(GPisMap3* g);
 
 using namespace gpis;
@@ -148,6 +148,10 @@ struct GPisMap3::Impl {
     std::vector<GPisMap3*> peers;
     void* d_send = nullptr; size_t cap_send = 0;
     void* d_recv = nullptr; size_t cap_recv = 0;
+    float* h_xstage = nullptr; size_t cap_xstage = 0;     // multi-device test(): page-locked staging of this rank's query blocks ...
+    float* h_rstage = nullptr; size_t cap_rstage = 0;     // ... and of their results
+    std::vector<hipStream_t> peer_streams;       // in-library multi-device exchange: one copy stream per source rank
+    double stat_exchange_bytes = 0.0;            // bytes this rank received in the last in-library exchange
     static constexpr int kQueryBlock = 65536;
 
     Impl(const GPisMap3Param& par, const camParam& c)
@@ -169,6 +173,9 @@ struct GPisMap3::Impl {
     ~Impl() {
         (void)store.train_finish();
         (void)hipFree(d_x); (void)hipFree(d_res); (void)hipFree(d_send); (void)hipFree(d_recv);
+        for (hipStream_t ps : peer_streams) if (ps) (void)hipStreamDestroy(ps);
+        if (h_xstage) (void)hipHostFree(h_xstage);
+        if (h_rstage) (void)hipHostFree(h_rstage);
         if (stream) (void)hipStreamDestroy(stream);
         if (train_stream) (void)hipStreamDestroy(train_stream);
         if (batch_stream) (void)hipStreamDestroy(batch_stream);
@@ -885,49 +892,62 @@ void GPisMap3::resetCam(camParam c) try {  // GPisMap3.cpp:117-123
     p_->vu_grid.clear();
 } catch (const std::exception& e) { nothrow_report("GPisMap3::resetCam", e.what()); } catch (...) { nothrow_report("GPisMap3::resetCam", "unknown exception"); }
 
-// The models every rank trained travel to every other rank: pack on the owner's device, hipMemcpyPeer into the receiver's
-// buffer, unpack as predict-only models, then every rank builds its cluster table.  Bytes per frame and link: a rank sends
-// its (2 K^2 + 20 K)-byte records once to each of the other n-1 ranks (synthetic scene: ~0.9 GB / n per rank and frame).
+// The models every rank trained travel to every other rank: pack on the owner's device (records back to back at their own
+// sizes), hipMemcpyPeerAsync into the receiver's buffer -- one stream per source, so the copies of the later sources run
+// under the unpacking of the earlier ones --, unpack as predict-only models, then every rank builds its cluster table.
+// Bytes: a rank sends its records (2 K^2 + 20 K bytes each) once to each of the other n-1 ranks and nothing else
+// (synthetic scene, F = 5: 1.3 GB of records per frame in total; round 3 padded every record to the largest: 5.8 GB).
 static int exchange_models_multi(GPisMap3* self) {
     GPisMap3::Impl& m0 = *self->impl();
     const int world = 1 + (int)m0.peers.size();
     auto inst = [&](int r) { return r == 0 ? self : m0.peers[r - 1]; };
-    std::vector<int> info(2 + world);
-    if (gpis3_impl_shard_info(self, info.data(), (int)info.size())) return GPIS_ERR_STATE;
-    long long stride = 256;
-    for (int r = 0; r < world; ++r) stride = std::max(stride, gpis3_impl_shard_packed_bytes(inst(r)));
-    stride = (stride + 255) / 256 * 256;
-    std::vector<int> cnt(info.begin() + 2, info.end());      // clusters trained by rank r (same on every rank)
+    std::vector<size_t> bytes(world);                          // record bytes of rank r (the same on every rank)
+    for (int r = 0; r < world; ++r) { const long long b = gpis3_impl_shard_bytes(self, r); if (b < 0) return GPIS_ERR_STATE; bytes[r] = (size_t)b; }
     std::vector<int> rc(world, GPIS_OK);
     auto ensure = [](void*& p, size_t& cap, size_t need) -> int {
         if (need <= cap) return GPIS_OK;
         (void)hipFree(p); p = nullptr; cap = 0;
-        if (hipMalloc(&p, need) != hipSuccess) return GPIS_ERR_HIP;
-        cap = need;
+        if (hipMalloc(&p, need + need / 4) != hipSuccess) return GPIS_ERR_HIP;
+        cap = need + need / 4;
         return GPIS_OK;
     };
     for_each_rank(m0, [&](int r, GPisMap3*) {                 // pack, every rank on its device
         GPisMap3::Impl& m = *inst(r)->impl();
         DeviceScope ds(m.device);
-        if (cnt[r] == 0) return;
-        rc[r] = ensure(m.d_send, m.cap_send, (size_t)cnt[r] * stride);
-        if (!rc[r]) rc[r] = gpis3_impl_shard_pack(inst(r), m.d_send, stride, nullptr);
+        if (bytes[r] == 0) return;
+        rc[r] = ensure(m.d_send, m.cap_send, bytes[r]);
+        if (!rc[r]) rc[r] = gpis3_impl_shard_pack(inst(r), m.d_send, nullptr);
     });
     for (int r = 0; r < world; ++r) if (rc[r]) return rc[r];
     for_each_rank(m0, [&](int q, GPisMap3*) {                 // receive + unpack, every rank on its device
         GPisMap3::Impl& m = *inst(q)->impl();
         DeviceScope ds(m.device);
         size_t total = 0;
-        for (int r = 0; r < world; ++r) if (r != q) total += (size_t)cnt[r] * stride;
+        for (int r = 0; r < world; ++r) if (r != q) total += bytes[r];
+        m.stat_exchange_bytes = (double)total;
         if (total) rc[q] = ensure(m.d_recv, m.cap_recv, total);
-        size_t off = 0;
-        for (int r = 0; r < world && !rc[q]; ++r) {
-            if (r == q || cnt[r] == 0) continue;
+        if (rc[q]) return;
+        if ((int)m.peer_streams.size() < world) {
+            m.peer_streams.resize(world, nullptr);
+            for (int r = 0; r < world; ++r) {
+                if (r == q) continue;
+                if (hipStreamCreateWithFlags(&m.peer_streams[r], hipStreamNonBlocking) != hipSuccess) { rc[q] = GPIS_ERR_HIP; return; }
+                const int sd = inst(r)->impl()->device;
+                if (sd != m.device) { (void)hipDeviceEnablePeerAccess(sd, 0); (void)hipGetLastError(); }   // (once; "already enabled" is fine)
+            }
+        }
+        std::vector<size_t> off(world, 0);
+        size_t o = 0;
+        for (int r = 0; r < world; ++r) {                      // all copies in flight first
+            if (r == q || bytes[r] == 0) continue;
+            off[r] = o; o += bytes[r];
             GPisMap3::Impl& src = *inst(r)->impl();
-            const size_t bytes = (size_t)cnt[r] * stride;
-            if (hipMemcpyPeer((char*)m.d_recv + off, m.device, src.d_send, src.device, bytes) != hipSuccess) { rc[q] = GPIS_ERR_HIP; break; }
-            rc[q] = gpis3_impl_shard_unpack(inst(q), r, (char*)m.d_recv + off, cnt[r], stride, nullptr);
-            off += bytes;
+            if (hipMemcpyPeerAsync((char*)m.d_recv + off[r], m.device, src.d_send, src.device, bytes[r], m.peer_streams[r]) != hipSuccess) { rc[q] = GPIS_ERR_HIP; return; }
+        }
+        for (int r = 0; r < world && !rc[q]; ++r) {
+            if (r == q || bytes[r] == 0) continue;
+            if (hipStreamSynchronize(m.peer_streams[r]) != hipSuccess) { rc[q] = GPIS_ERR_HIP; break; }
+            rc[q] = gpis3_impl_shard_unpack(inst(q), r, (char*)m.d_recv + off[r], nullptr);
         }
         if (!rc[q]) rc[q] = gpis3_impl_shard_finish(inst(q));
     });
@@ -1005,21 +1025,38 @@ bool GPisMap3::test(float* x, int dim, int leng, float* res) try {  // GPisMap3.
     std::vector<int> frc(world, 0);
     for_each_rank(m0, [&](int r, GPisMap3* q) {
         GPisMap3* g = r == 0 ? this : q;
-        std::vector<float> xr, rr;
+        Impl& mr = *g->impl();
+        // this rank's blocks gathered into PAGE-LOCKED staging (the copies to and from the device are then true DMA transfers
+        // straight out of / into these buffers; pageable vectors cost one more pass through the runtime's own staging each way)
+        size_t nq = 0;
+        for (int b = r; b < nblk; b += world) nq += (size_t)(std::min(leng, (b + 1) * B) - b * B);
+        if (nq == 0) return;
+        DeviceScope ds(mr.device);
+        auto ensure_pinned = [](float*& p, size_t& cap, size_t need) -> bool {
+            if (need <= cap) return true;
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            const size_t want = need + need / 2;
+            if (hipHostMalloc((void**)&p, sizeof(float) * want) != hipSuccess) { p = nullptr; return false; }
+            cap = want;
+            return true;
+        };
+        if (!ensure_pinned(mr.h_xstage, mr.cap_xstage, 3 * nq) || !ensure_pinned(mr.h_rstage, mr.cap_rstage, 8 * nq)) { okv[r] = 0; frc[r] = GPIS_ERR_HIP; return; }
+        size_t o = 0;
         for (int b = r; b < nblk; b += world) {
             const int lo = b * B, hi = std::min(leng, lo + B);
-            xr.insert(xr.end(), x + (size_t)3 * lo, x + (size_t)3 * hi);
-            rr.insert(rr.end(), res + (size_t)8 * lo, res + (size_t)8 * hi);
+            std::memcpy(mr.h_xstage + 3 * o, x + (size_t)3 * lo, sizeof(float) * 3 * (size_t)(hi - lo));
+            std::memcpy(mr.h_rstage + 8 * o, res + (size_t)8 * lo, sizeof(float) * 8 * (size_t)(hi - lo));   // (callers pre-fill res)
+            o += (size_t)(hi - lo);
         }
-        if (xr.empty()) return;
-        okv[r] = g->test_one(xr.data(), 3, (int)(xr.size() / 3), rr.data()) ? 1 : 0;
-        frc[r] = g->impl()->fail_rc;
+        okv[r] = g->test_one(mr.h_xstage, 3, (int)nq, mr.h_rstage) ? 1 : 0;
+        frc[r] = mr.fail_rc;
         if (!okv[r]) return;
-        size_t off = 0;
+        o = 0;
         for (int b = r; b < nblk; b += world) {
             const int lo = b * B, hi = std::min(leng, lo + B);
-            std::memcpy(res + (size_t)8 * lo, rr.data() + off, sizeof(float) * 8 * (size_t)(hi - lo));
-            off += (size_t)8 * (hi - lo);
+            std::memcpy(res + (size_t)8 * lo, mr.h_rstage + 8 * o, sizeof(float) * 8 * (size_t)(hi - lo));
+            o += (size_t)(hi - lo);
         }
     });
     for (int r = 0; r < world; ++r) if (!okv[r]) { p_->fail_rc = frc[r]; return false; }
@@ -1096,38 +1133,42 @@ int gpis3_impl_shard_info(GPisMap3* g, int* out, int n) {
     for (auto& j : m.shard_jobs) { ++out[2 + j.owner]; if (j.owner == m.shard_rank) ++out[1]; }
     return GPIS_OK;
 }
-static void shard_slots(GPisMap3::Impl& m, int owner, std::vector<int>& slots) {
-    slots.clear();
-    for (auto& j : m.shard_jobs) if (j.owner == owner) slots.push_back(j.slot);
+// The records of one owner, in the frame's job order, back to back at their own sizes: slots and byte offsets (n + 1
+// entries).  Every rank can lay out every rank's buffer: N and ng of all jobs of the frame are known everywhere.
+static void shard_layout(GPisMap3::Impl& m, int owner, std::vector<int>& slots, std::vector<size_t>& offs) {
+    slots.clear(); offs.assign(1, 0);
+    for (auto& j : m.shard_jobs)
+        if (j.owner == owner) {
+            const int K = j.n + 3 * j.ng, ld = (K + 1 + 31) / 32 * 32;
+            slots.push_back(j.slot);
+            offs.push_back(offs.back() + packed_model_bytes(ld, j.n));
+        }
 }
-long long gpis3_impl_shard_packed_bytes(GPisMap3* g) {
+long long gpis3_impl_shard_bytes(GPisMap3* g, int owner) {
     GPisMap3::Impl& m = *g->impl();
-    size_t mx = 256;    // every rank can size every record: N and ng of all jobs are known everywhere
-    for (auto& j : m.shard_jobs) {
-        const int K = j.n + 3 * j.ng, ld = (K + 1 + 31) / 32 * 32;
-        mx = std::max(mx, packed_model_bytes(ld, j.n));
-    }
-    return (long long)mx;
+    if (owner < 0 || owner >= m.shard_world) return GPIS_ERR_ARG;
+    std::vector<int> slots; std::vector<size_t> offs;
+    shard_layout(m, owner, slots, offs);
+    return (long long)offs.back();
 }
-int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, long long stride, void* stream) {
+int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, void* stream) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
-    std::vector<int> slots;
-    shard_slots(m, m.shard_rank, slots);
+    std::vector<int> slots; std::vector<size_t> offs;
+    shard_layout(m, m.shard_rank, slots, offs);
     if (slots.empty()) return GPIS_OK;
     if (!d_buf) return GPIS_ERR_ARG;
-    return m.store.pack_models(slots.data(), (int)slots.size(), d_buf, (size_t)stride, stream ? (hipStream_t)stream : m.stream);
+    return m.store.pack_models(slots.data(), (int)slots.size(), d_buf, 0, stream ? (hipStream_t)stream : m.stream, offs.data());
 }
-int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, int n, long long stride, void* stream) {
+int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, void* stream) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     if (owner < 0 || owner >= m.shard_world || owner == m.shard_rank) return GPIS_ERR_ARG;
-    std::vector<int> slots;
-    shard_slots(m, owner, slots);
-    if ((int)slots.size() != n) return GPIS_ERR_ARG;
-    if (n == 0) return GPIS_OK;
+    std::vector<int> slots; std::vector<size_t> offs;
+    shard_layout(m, owner, slots, offs);
+    if (slots.empty()) return GPIS_OK;
     if (!d_buf) return GPIS_ERR_ARG;
-    return m.store.unpack_models(d_buf, n, (size_t)stride, slots.data(), stream ? (hipStream_t)stream : m.stream);
+    return m.store.unpack_models(d_buf, (int)slots.size(), 0, slots.data(), stream ? (hipStream_t)stream : m.stream, offs.data());
 }
 int gpis3_impl_shard_finish(GPisMap3* g) {
     GPisMap3::Impl& m = *g->impl();
@@ -1142,14 +1183,14 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     m.finish_training();      // (the training time of the last batch is read off its events)
-    double v[23] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[24] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
                     m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK,
-                    (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs};
-    for (int i = 0; i < n && i < 23; ++i) out[i] = v[i];
+                    (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs, m.stat_exchange_bytes};
+    for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];
 }
 // join the training the last update() left in flight; returns the update status (0: fine)
 int gpis3_impl_sync(GPisMap3* g) {

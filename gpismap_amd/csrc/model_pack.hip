@@ -1,8 +1,11 @@
 // Packed cluster models for the multi-GPU exchange (per-cluster training shards across the GPUs of a
-// node; what test() needs from a trained cluster travels in ONE padded record per model so that an RCCL all-gather of
-// equal-size slots assembles the map on every rank).  The reference has no counterpart (single process).
+// node; what test() needs from a trained cluster travels in ONE record per model).  Records have their OWN size --
+// pk_bytes(ld, N), a multiple of 256 -- and sit back to back at the byte offsets the caller gives (every rank can compute
+// every rank's offsets: the sizes of all jobs of a frame are known everywhere), so an exchange moves the records' bytes and
+// nothing else (round 3 padded every record to the frame's largest: 4.5 x the bytes at F = 5).  The reference has no
+// counterpart (single process).
 //
-// Record layout (stride bytes, multiple of 256):
+// Record layout:
 //   [0, 64)      header: int dim, N, ng, K, ld, nb; float scale; int reserved[9]
 //   [64, ..)     rowinfo[ld] (int)  |  x4[N][4] (float)  |  Xt tiles [ld/32 (ld/32 + 1) / 2][1024] (float), each piece 256-B aligned
 // Only what K4 reads is shipped (Xt carries alpha in row K): 2 K^2 + 20 K bytes instead of the 10 K^2 of a trained model.
@@ -24,9 +27,9 @@ size_t packed_model_bytes(int ld, int N) { return pk_bytes(ld, N); }
 // storage of the right size)
 template <bool PACK>
 __global__ __launch_bounds__(256) void model_pack_kernel(const ClusterModel* __restrict__ models, const int* __restrict__ slots,
-                                                         char* __restrict__ buf, size_t stride) {
+                                                         char* __restrict__ buf, const unsigned long long* __restrict__ offs) {
     const ClusterModel m = models[slots[blockIdx.x]];
-    char* rec = buf + (size_t)blockIdx.x * stride;
+    char* rec = buf + offs[blockIdx.x];
     const int tid = threadIdx.x;
     if (PACK && tid == 0) {
         int* h = reinterpret_cast<int*>(rec);
@@ -50,10 +53,19 @@ __global__ __launch_bounds__(256) void model_pack_kernel(const ClusterModel* __r
     }
 }
 
-void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slots, int n, char* d_buf, size_t stride, hipStream_t s) {
+void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slots, int n, char* d_buf, const unsigned long long* d_offs, hipStream_t s) {
     if (n <= 0) return;
-    if (pack) hipLaunchKernelGGL((model_pack_kernel<true>), dim3(n), dim3(256), 0, s, d_models, d_slots, d_buf, stride);
-    else hipLaunchKernelGGL((model_pack_kernel<false>), dim3(n), dim3(256), 0, s, d_models, d_slots, d_buf, stride);
+    if (pack) hipLaunchKernelGGL((model_pack_kernel<true>), dim3(n), dim3(256), 0, s, d_models, d_slots, d_buf, d_offs);
+    else hipLaunchKernelGGL((model_pack_kernel<false>), dim3(n), dim3(256), 0, s, d_models, d_slots, d_buf, d_offs);
+}
+
+// the 64-byte headers of n records gathered into one array (one copy to the host instead of n)
+__global__ void model_headers_kernel(const char* __restrict__ buf, const unsigned long long* __restrict__ offs, int n, int* __restrict__ out) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), w = threadIdx.x & 15;
+    if (i < n) out[16 * i + w] = reinterpret_cast<const int*>(buf + offs[i])[w];
+}
+void model_headers_launch(const char* d_buf, const unsigned long long* d_offs, int n, int* d_out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(model_headers_kernel, dim3((n + 15) / 16), dim3(256), 0, s, d_buf, d_offs, n, d_out);
 }
 
 }  // namespace gpis

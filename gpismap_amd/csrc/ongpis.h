@@ -80,10 +80,12 @@ public:
                   hipStream_t s);
     // ---- multi-GPU exchange (model_pack.hip): packed records of what K4 needs from a trained model ----
     size_t packed_bytes(const int* slots, int n) const;                 // largest record among the listed models
-    int pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s);
+    // record i at byte offset offs[i] of d_buf (offs == nullptr: i * stride; otherwise stride is ignored and the records
+    // sit back to back at their own sizes: offs has n + 1 entries, the last one the end of the buffer)
+    int pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs = nullptr);
     // records -> models.  slots_inout[i] < 0: a new slot is created and returned there; else that slot is (re)used.
     // The models are predict-only (no factor, no training scratch).
-    int unpack_models(const void* d_buf, int n, size_t stride, int* slots_inout, hipStream_t s);
+    int unpack_models(const void* d_buf, int n, size_t stride, int* slots_inout, hipStream_t s, const size_t* offs = nullptr);
     // Kernel matrix only (the separate build kernel on caller-given arrays, no gather rule): x [N][dim], gidx [N] running
     // gradient index or -1, sigx / sigg [N]; K_out receives the K x K lower triangle, column-major (ld = K).  Parity of
     // covFnc.cpp:142-256 / :317-402 against committed fixtures.
@@ -189,7 +191,8 @@ int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hi
 
 // kernels (ongpis_train.hip / ongpis_test.hip)
 size_t packed_model_bytes(int ld, int N);
-void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slots, int n, char* d_buf, size_t stride, hipStream_t s);
+void model_pack_launch(bool pack, const ClusterModel* d_models, const int* d_slots, int n, char* d_buf, const unsigned long long* d_offs, hipStream_t s);
+void model_headers_launch(const char* d_buf, const unsigned long long* d_offs, int n, int* d_out, hipStream_t s);
 void ongpis_launch_gather(const ClusterModel* d_models, const int* d_jobs, int njobs, const int* d_ids,
                           const float* d_pts, int pts_cap, hipStream_t s);
 void ongpis_launch_buildK(const ClusterModel* d_models, const int* d_jobs, int njobs, hipStream_t s);

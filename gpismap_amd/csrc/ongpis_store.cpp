@@ -742,65 +742,85 @@ size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
 
 // Records of models that are NOT trained (allocation failure, refused size) travel as "absent" records -- a header with
 // K = 0 -- so that every rank still reaches the collective and the receivers mark those slots untrained.
-int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s) {
+// Device scratch of a pack / unpack call: the slot list (n ints), the byte offset of every record (n x 8 bytes) and, for
+// unpack, the gathered headers (16 n ints), in d_slots_.
+static size_t pk_scratch_ints(int n) { return (size_t)n + 2 * (size_t)n + 16 * (size_t)n + 8; }
+
+int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs) {
     if (n <= 0) return GPIS_OK;
     { const int erc = ensure_inverses(s); if (erc) return erc; }
-    if (stride % 256 != 0) return GPIS_ERR_ARG;
-    std::vector<int> present, pidx;
+    if (!offs && stride % 256 != 0) return GPIS_ERR_ARG;
+    auto rec_off = [&](int i) { return offs ? offs[i] : (size_t)i * stride; };
+    auto rec_room = [&](int i) { return offs ? offs[i + 1] - offs[i] : stride; };
+    std::vector<int> present;
+    std::vector<unsigned long long> poff;
     for (int i = 0; i < n; ++i) {
+        if (offs && (offs[i] % 256 != 0 || offs[i + 1] < offs[i])) return GPIS_ERR_ARG;
         const ClusterModel* m = model(slots[i]);
         if (m && m->base && m->Xt) {
-            if (packed_model_bytes(m->ld, m->N) > stride) return GPIS_ERR_ARG;
-            present.push_back(slots[i]); pidx.push_back(i);
-        }
+            if (packed_model_bytes(m->ld, m->N) > rec_room(i)) return GPIS_ERR_ARG;
+            present.push_back(slots[i]); poff.push_back((unsigned long long)rec_off(i));
+        } else if (rec_room(i) < 64) return GPIS_ERR_ARG;
     }
     int rc = sync_models(s);
     if (rc) return rc;
     if ((int)present.size() < n) {      // absent records: zero headers (K = 0)
         for (int i = 0; i < n; ++i) {
             const ClusterModel* m = model(slots[i]);
-            if (!(m && m->base && m->Xt)) GPIS_HIP(hipMemsetAsync((char*)d_buf + (size_t)i * stride, 0, 64, s));
+            if (!(m && m->base && m->Xt)) GPIS_HIP(hipMemsetAsync((char*)d_buf + rec_off(i), 0, 64, s));
         }
     }
     if (!present.empty()) {
-        if (n > cap_slots_) {
-            (void)hipFree(d_slots_); d_slots_ = nullptr;
-            GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * (size_t)(n + n / 2 + 64)));
-            cap_slots_ = n + n / 2 + 64;
+        const int np = (int)present.size();
+        if ((int)pk_scratch_ints(n) > cap_slots_) {
+            (void)hipFree(d_slots_); d_slots_ = nullptr; cap_slots_ = 0;
+            const size_t cap = pk_scratch_ints(n + n / 2 + 64);
+            GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * cap));
+            cap_slots_ = (int)cap;
         }
-        // the kernel packs record blockIdx of the list it is given: pack the present models record by record position
-        if ((int)present.size() == n) {
-            GPIS_HIP(hipMemcpyAsync(d_slots_, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-            model_pack_launch(true, d_models_, d_slots_, n, (char*)d_buf, stride, s);
-        } else {
-            for (size_t k = 0; k < present.size(); ++k) {       // rare path: one launch per present record
-                GPIS_HIP(hipMemcpyAsync(d_slots_, &present[k], sizeof(int), hipMemcpyHostToDevice, s));
-                model_pack_launch(true, d_models_, d_slots_, 1, (char*)d_buf + (size_t)pidx[k] * stride, stride, s);
-                GPIS_HIP(hipStreamSynchronize(s));
-            }
-        }
+        unsigned long long* d_offs = reinterpret_cast<unsigned long long*>(d_slots_ + ((n + 1) & ~1));
+        GPIS_HIP(hipMemcpyAsync(d_slots_, present.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, s));
+        GPIS_HIP(hipMemcpyAsync(d_offs, poff.data(), sizeof(unsigned long long) * (size_t)np, hipMemcpyHostToDevice, s));
+        model_pack_launch(true, d_models_, d_slots_, np, (char*)d_buf, d_offs, s);
         GPIS_HIP(hipGetLastError());
     }
-    GPIS_HIP(hipStreamSynchronize(s));
+    GPIS_HIP(hipStreamSynchronize(s));     // (the host vectors above were the sources of asynchronous copies)
     return GPIS_OK;
 }
 
-int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slots, hipStream_t s) {
+int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slots, hipStream_t s, const size_t* offs) {
     if (n <= 0) return GPIS_OK;
     (void)train_finish();
-    if (stride % 256 != 0) return GPIS_ERR_ARG;
+    if (!offs && stride % 256 != 0) return GPIS_ERR_ARG;
+    auto rec_off = [&](int i) { return offs ? offs[i] : (size_t)i * stride; };
+    auto rec_room = [&](int i) { return offs ? offs[i + 1] - offs[i] : stride; };
+    for (int i = 0; i < n; ++i) if (offs && (offs[i] % 256 != 0 || offs[i + 1] < offs[i] + 64)) return GPIS_ERR_ARG;
+    if ((int)pk_scratch_ints(n) > cap_slots_) {
+        (void)hipFree(d_slots_); d_slots_ = nullptr; cap_slots_ = 0;
+        const size_t cap = pk_scratch_ints(n + n / 2 + 64);
+        GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * cap));
+        cap_slots_ = (int)cap;
+    }
+    unsigned long long* d_offs = reinterpret_cast<unsigned long long*>(d_slots_ + ((n + 1) & ~1));
+    int* d_hdr = d_slots_ + ((n + 1) & ~1) + 2 * n;
+    std::vector<unsigned long long> aoff(n);
+    for (int i = 0; i < n; ++i) aoff[i] = (unsigned long long)rec_off(i);
     std::vector<int> hdr((size_t)16 * n);
-    GPIS_HIP(hipMemcpy2DAsync(hdr.data(), 64, d_buf, stride, 64, (size_t)n, hipMemcpyDeviceToHost, s));
+    GPIS_HIP(hipMemcpyAsync(d_offs, aoff.data(), sizeof(unsigned long long) * (size_t)n, hipMemcpyHostToDevice, s));
+    model_headers_launch((const char*)d_buf, d_offs, n, d_hdr, s);
+    GPIS_HIP(hipGetLastError());
+    GPIS_HIP(hipMemcpyAsync(hdr.data(), d_hdr, sizeof(int) * 16 * (size_t)n, hipMemcpyDeviceToHost, s));
     GPIS_HIP(hipStreamSynchronize(s));
     std::vector<int> created;            // slots made by this call: released again if a later record is refused
     auto bail = [&](int rc) { for (int sl : created) release_slot(sl); return rc; };
-    std::vector<int> present, pidx;
+    std::vector<int> present;
+    std::vector<unsigned long long> poff;
     for (int i = 0; i < n; ++i) {
         const int* h = &hdr[(size_t)16 * i];
         const int dim = h[0], N = h[1], ng = h[2], K = h[3], ld = h[4];
         const bool absent = (K == 0 && N == 0);
         if (!absent && (dim != dim_ || N <= 0 || ng < 0 || ng > N || K != N + dim * ng || ld != (int)align_up((size_t)K + 1, 32) ||
-                        packed_model_bytes(ld, N) > stride))
+                        packed_model_bytes(ld, N) > rec_room(i)))
             return bail(GPIS_ERR_ARG);
         if (slots[i] < 0) { slots[i] = new_slot(); created.push_back(slots[i]); }
         else if (slots[i] >= (int)models_.size() || !live_[slots[i]]) return bail(GPIS_ERR_ARG);
@@ -814,26 +834,15 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
         if (slots[i] < (int)xstale_.size()) xstale_[slots[i]] = 0;     // (an imported model carries its X)
         int rc = alloc_model(slots[i], N, ng, kAllocPredictOnly);
         if (rc) return bail(rc);
-        present.push_back(slots[i]); pidx.push_back(i);
+        present.push_back(slots[i]); poff.push_back(aoff[i]);
     }
     int rc = sync_models(s);
     if (rc) return bail(rc);
     if (!present.empty()) {
-        if (n > cap_slots_) {
-            (void)hipFree(d_slots_); d_slots_ = nullptr;
-            GPIS_HIP(hipMalloc(&d_slots_, sizeof(int) * (size_t)(n + n / 2 + 64)));
-            cap_slots_ = n + n / 2 + 64;
-        }
-        if ((int)present.size() == n) {
-            GPIS_HIP(hipMemcpyAsync(d_slots_, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
-            model_pack_launch(false, d_models_, d_slots_, n, (char*)const_cast<void*>(d_buf), stride, s);
-        } else {
-            for (size_t k = 0; k < present.size(); ++k) {
-                GPIS_HIP(hipMemcpyAsync(d_slots_, &present[k], sizeof(int), hipMemcpyHostToDevice, s));
-                model_pack_launch(false, d_models_, d_slots_, 1, (char*)const_cast<void*>(d_buf) + (size_t)pidx[k] * stride, stride, s);
-                GPIS_HIP(hipStreamSynchronize(s));
-            }
-        }
+        const int np = (int)present.size();
+        GPIS_HIP(hipMemcpyAsync(d_slots_, present.data(), sizeof(int) * (size_t)np, hipMemcpyHostToDevice, s));
+        GPIS_HIP(hipMemcpyAsync(d_offs, poff.data(), sizeof(unsigned long long) * (size_t)np, hipMemcpyHostToDevice, s));
+        model_pack_launch(false, d_models_, d_slots_, np, (char*)const_cast<void*>(d_buf), d_offs, s);
         GPIS_HIP(hipGetLastError());
     }
     GPIS_HIP(hipStreamSynchronize(s));

@@ -14,7 +14,8 @@ update(): two modes.  *Replicated* training: every rank runs the same update() a
 models -- no exchange at all.  *Sharded* training (`GPisMap3.set_shard` + `exchange_models`): every
 rank runs the same host logic but factorises only its share of the frame's clusters (greedy
 longest-processing-time partition by K^3, computed identically on every rank), then the packed
-models (what K4 needs: 2 K^2 + 20 K bytes each) are all-gathered as equal-size records.
+models (what K4 needs: 2 K^2 + 20 K bytes each, records back to back at their own sizes) are
+all-gathered in one collective over slots padded to the largest RANK total.
 `shard_clusters` is the same partition for harnesses that drive the kernel-level C-ABI themselves
 (BASELINE config 5)."""
 import heapq
@@ -102,49 +103,55 @@ def shard_clusters(costs, world):
     return out
 
 
-def _all_gather_records(send, counts, stride, world, rank, device, host_staged):
-    """All-gather of per-rank record buffers (uint8 [counts[r] * stride]) padded to the largest count.
-    Returns a [world, max_count * stride] uint8 tensor on `device`."""
+def _all_gather_bytes(send, nbytes, world, rank, device, host_staged):
+    """All-gather of per-rank byte buffers of DIFFERENT lengths nbytes[r] (uint8): one collective over slots padded to the
+    largest rank total.  Returns a [world, max(nbytes)] uint8 tensor on `device` (row r valid up to nbytes[r])."""
     import torch
     import torch.distributed as dist
-    mx = max(counts)
-    pad = torch.zeros(mx * stride, dtype=torch.uint8, device=device)
-    if counts[rank]:
-        pad[:counts[rank] * stride].copy_(send[:counts[rank] * stride])
+    mx = max(max(nbytes), 256)
+    pad = torch.empty(mx, dtype=torch.uint8, device=device)
+    if nbytes[rank]:
+        pad[:nbytes[rank]].copy_(send[:nbytes[rank]])
     if host_staged:                               # gloo rehearsal: no device collectives
         torch.cuda.synchronize()
         hp = pad.cpu()
         outs = [torch.empty_like(hp) for _ in range(world)]
         dist.all_gather(outs, hp)
         return torch.stack(outs).to(device)
-    out = torch.empty((world, mx * stride), dtype=torch.uint8, device=device)
+    out = torch.empty((world, mx), dtype=torch.uint8, device=device)
     dist.all_gather_into_tensor(out.view(-1), pad)
     return out
 
 
+def _all_gather_records(send, counts, stride, world, rank, device, host_staged):
+    """Equal-size records (kernel-level store API): counts[r] records of `stride` bytes per rank."""
+    return _all_gather_bytes(send, [c * stride for c in counts], world, rank, device, host_staged)
+
+
 def exchange_models(gm, world, rank, device, host_staged=False):
-    """Complete a sharded GPisMap3.update(): pack the locally trained models, all-gather the records (RCCL
-    all_gather_into_tensor of equal-size padded slots; host-staged over gloo in the rehearsal), unpack the other
-    ranks' models and build the cluster table.  Returns (clusters of the frame, bytes received)."""
+    """Complete a sharded GPisMap3.update(): pack the locally trained models (records back to back at their OWN sizes),
+    all-gather the buffers (ONE RCCL all_gather_into_tensor over slots padded to the largest RANK total -- the K^3-balanced
+    partition makes the totals near-equal; host-staged over gloo in the rehearsal), unpack the other ranks' models and
+    build the cluster table.  Returns (clusters of the frame, record bytes received, bytes the collective delivered
+    including the padding of the shorter ranks, sum of all ranks' record bytes)."""
     import torch
-    import torch.distributed as dist
     if world == 1:
         gm.shard_finish()
-        return 0, 0
+        return 0, 0, 0, 0
     total, nloc, counts = gm.shard_info()
-    stride = gm.shard_packed_bytes()              # identical on every rank (sizes of all jobs are known everywhere)
     if total == 0:
         gm.shard_finish()
-        return 0, 0
-    send = torch.empty(max(1, nloc) * stride, dtype=torch.uint8, device=device)
-    gm.shard_pack(send.data_ptr(), stride, torch.cuda.current_stream().cuda_stream)
-    allrec = _all_gather_records(send, counts, stride, world, rank, device, host_staged)
+        return 0, 0, 0, 0
+    nbytes = [gm.shard_bytes(r) for r in range(world)]          # identical on every rank (sizes of all jobs are known everywhere)
+    send = torch.empty(max(256, nbytes[rank]), dtype=torch.uint8, device=device)
+    gm.shard_pack(send.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    allrec = _all_gather_bytes(send, nbytes, world, rank, device, host_staged)
     torch.cuda.synchronize()
     for r in range(world):
-        if r != rank and counts[r]:
-            gm.shard_unpack(r, allrec[r].data_ptr(), counts[r], stride, torch.cuda.current_stream().cuda_stream)
+        if r != rank and nbytes[r]:
+            gm.shard_unpack(r, allrec[r].data_ptr(), torch.cuda.current_stream().cuda_stream)
     gm.shard_finish()
-    return total, (sum(counts) - nloc) * stride
+    return total, sum(nbytes) - nbytes[rank], (world - 1) * max(nbytes), sum(nbytes)
 
 
 def exchange_store_models(st, local_models, world, rank, device, host_staged=False):

@@ -65,20 +65,24 @@ int   gpis3_device(void* map);                                 /* device the map
 /* ---- multi-GPU: sharded cluster training (one process per GPU).  Every rank runs the same update()
  * (host logic is deterministic, so trees, cluster sets and model slots agree), but after gpis3_set_shard(rank, world)
  * it TRAINS only its share of the frame's clusters (greedy longest-processing-time partition by K^3).  The caller then
- * moves the packed models between the ranks (e.g. RCCL all-gather of equal-size records) and completes the update:
+ * moves the packed models between the ranks and completes the update.  A rank's records (what prediction reads of each of
+ * its models: 2 K^2 + 20 K bytes) sit BACK TO BACK at their own sizes in the frame's job order; every rank can size every
+ * rank's buffer (gpis3_shard_bytes), so an exchange moves the records' bytes and no padding between them:
  *   gpis3_update(...);                                  trains the local share, defers the cluster table
  *   gpis3_shard_info(map, out, 2 + world)               out[0] = clusters of this frame, out[1] = local ones,
  *                                                       out[2 + r] = clusters rank r trains
- *   stride = max over ranks of gpis3_shard_packed_bytes(map)
- *   gpis3_shard_pack(map, d_send, stride, stream)       local models -> records, in the frame's job order
- *   gpis3_shard_unpack(map, r, d_recv_r, n_r, stride, stream)   for every other rank r
+ *   gpis3_shard_bytes(map, r)                           bytes of rank r's records (the same answer on every rank)
+ *   gpis3_shard_pack(map, d_send, stream)               local models -> d_send[0 .. gpis3_shard_bytes(map, rank))
+ *   ... transport: e.g. one RCCL all_gather_into_tensor of buffers padded to the largest RANK total (the K^3-balanced
+ *       partition makes the totals near-equal), grouped send/recv, or hipMemcpyPeerAsync inside one process ...
+ *   gpis3_shard_unpack(map, r, d_recv_r, stream)        for every other rank r
  *   gpis3_shard_finish(map)                             builds the cluster table: test() is valid again
  * With world = 1 (default) update() is complete on return and none of the calls is needed. */
 int   gpis3_set_shard(void* map, int rank, int world);
 int   gpis3_shard_info(void* map, int* out, int n);
-long long gpis3_shard_packed_bytes(void* map);
-int   gpis3_shard_pack(void* map, void* d_buf, long long stride, void* hip_stream);
-int   gpis3_shard_unpack(void* map, int owner, const void* d_buf, int n, long long stride, void* hip_stream);
+long long gpis3_shard_bytes(void* map, int owner);
+int   gpis3_shard_pack(void* map, void* d_buf, void* hip_stream);
+int   gpis3_shard_unpack(void* map, int owner, const void* d_buf, void* hip_stream);
 int   gpis3_shard_finish(void* map);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */

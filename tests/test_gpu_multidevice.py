@@ -28,6 +28,8 @@ def test_multi_device_map_equals_single_device_map(devices):
             one.set_camera(fr["cam"]); many.set_camera(fr["cam"])
         one.update(fr["depth"], fr["pose"]); many.update(fr["depth"], fr["pose"])
         assert np.array_equal(one.nodes(), many.nodes())
+        # the model exchange moved the other ranks' records at their own sizes and nothing else
+        assert many.stats()["exchange_bytes"] == sum(many.shard_bytes(r) for r in range(1, len(devices)))
         a, b = one.test(grid), many.test(grid)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
     many.reset()

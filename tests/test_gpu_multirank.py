@@ -38,7 +38,12 @@ def test_bench_rehearsal_is_bit_identical(world, train):
     st = d["stress"]
     assert st["finite"] and st["clusters"] == 96 and st["predict_evaluations"] == 96 * 64
     if train == "sharded":
-        assert d["exchange_bytes_per_frame"] > 0
+        # records travel at their own sizes -- what a rank receives is the other ranks' records and nothing
+        # else, and the one collective (slots padded to the largest RANK total) delivers at most 10 % more than that
+        rec, got, deliv = d["exchange_record_bytes_per_frame"], d["exchange_bytes_per_frame"], d["exchange_bytes_per_frame_delivered"]
+        assert rec > 0 and 0 < got < rec
+        assert got <= 1.1 * rec * (world - 1) / world + 4096, (got, rec)
+        assert deliv <= 1.1 * rec + 65536, (deliv, rec)             # padding of the shorter ranks' slots
     if world > 1:
         assert st["exchange_bytes_received_per_rank"] > 0
 

@@ -20,7 +20,15 @@ for N in 1 2 4 8; do
 import json, sys
 d = json.load(open(sys.argv[1]))
 pr = d["per_rank"]
-print("N=%s %-10s value %.3e pts/s  %.1f ms/step  update %.1f ms/frame  exchange %.1f MB/frame" % (sys.argv[2], sys.argv[3], d["value"], d["ms_per_step"], d["update_ms_per_frame"], d["exchange_bytes_per_frame"] / 1e6))
+n = int(sys.argv[2])
+print("N=%s %-10s value %.3e pts/s  %.1f ms/step  update %.1f ms/frame" % (sys.argv[2], sys.argv[3], d["value"], d["ms_per_step"], d["update_ms_per_frame"]))
+if d.get("exchange_record_bytes_per_frame"):
+    rec, got = d["exchange_record_bytes_per_frame"], d["exchange_bytes_per_frame"]
+    ex = [v for v in pr.get("exchange_ms_per_frame", []) if v > 0]
+    ms = max(ex) if ex else float("nan")
+    # all-gather over xGMI: a rank receives (n-1)/n of the records over its n-1 links; one link carries ~ records / n per frame
+    print("   exchange: records %.3f GB/frame, received per rank %.3f GB, %.2f ms/frame -> %.1f GB/s into each rank, %.3f GB and %.1f GB/s per link"
+          % (rec / 1e9, got / 1e9, ms, got / 1e6 / ms, rec / n / 1e9, rec / n / 1e6 / ms))
 print("   gp_evals/rank", [round(v / 1e6, 2) for v in pr["gp_evals"]], "M   k4_ms", [round(v, 1) for v in pr["k4_ms_per_step"]])
 if "pass_ms" in pr:
     print("   pass_ms", [round(v, 1) for v in pr["pass_ms"]], " gather_ms", [round(v, 1) for v in pr["gather_ms"]], " exchange_ms", [round(v, 1) for v in pr["exchange_ms_per_frame"]],
