@@ -164,8 +164,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
             xp = x4[p];
         }
+#ifndef K4_ABL_GENQ
+#define K4_ABL_GENQ 4     // (timing ablation: queries generated per lane; 4 = all)
+#endif
 #pragma unroll K4_GEN_UNROLL
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < K4_ABL_GENQ; ++j) {
             const int q = 8 * qs + 4 * qh + j;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < K && q < jcnt) {
@@ -199,6 +202,9 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         }
     };
     auto gen_tile = [&](int c, int qs, float* tbuf) {
+#ifdef K4_ABL_NOGEN      // (timing ablation only: wrong results)
+        return;
+#endif
         const int r0 = c * 32, r1 = min(K, r0 + 32) - 1;
         const int k0 = row_type(r0), k1 = row_type(r1);
         if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), c, qs, tbuf);
@@ -231,6 +237,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     };
 
     auto load_a = [&](float (&av)[16], int b, int c) {
+#ifdef K4_ABL_NOLOAD     // (timing ablation only: wrong results)
+        for (int g = 0; g < 16; ++g) av[g] = (float)(b + c + g);
+        return;
+#endif
         const int sbase = (b * (b + 1) / 2 + c) * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
