@@ -16,9 +16,11 @@
 #include <chrono>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <unordered_map>
 #include "../../include/GPisMap3.h"
 #include "flat_tree.h"
+#include "host_pool.h"
 #include "map_query.h"
 #include "obsgp.h"
 #include "ongpis.h"
@@ -206,7 +208,15 @@ struct GPisMap3::Impl {
     };
     void reeval_batch(const std::vector<int>& ids, std::vector<Stage2>& st, std::vector<float>& pval,
                       std::vector<float>& pvar);
+    // Stage 3 of a stored point's re-evaluation in two halves: reeval_math is a pure function of the point's state, its ObsGP
+    // answers, the pose and the settings (data-parallel over the points of the frame: host_pool.h); reeval_commit applies the
+    // outcome to the tree (sequential, in the reference's order).  reeval_apply = both, for the late arrivals.
+    struct ReevalOut { int kind = 0; float pos[3], grad[3], noise = 0.f, gnoise = 0.f; };   // 0 nothing, 1 inflate the noises, 2 move the point
+    ReevalOut reeval_math(const FlatPoint<3>& nd, const Stage2& st, const float* pval, const float* pvar) const;
+    void reeval_commit(int pid, const ReevalOut& o);
     void reeval_apply(int pid, const Stage2& st, const float* pval, const float* pvar);
+    std::unique_ptr<HostPool> hpool;
+    HostPool& pool() { if (!hpool) hpool.reset(new HostPool()); return *hpool; }
 };
 
 // ------------------------------------------------------------------ preprocess ----
@@ -300,7 +310,9 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
     std::vector<char> front(n, 0);
     std::vector<std::array<float, 3>> loc(n);
-    for (int i = 0; i < n; ++i) {
+    // (both host loops below are pure per point: on the host threads, host_pool.h)
+    pool().parallel_for(n, [&](int lo_, int hi_) {
+    for (int i = lo_; i < hi_; ++i) {
         const float* pos = tree.pts[ids[i]].pos;
         float x_loc = pose_R[0] * (pos[0] - pose_tr[0]) + pose_R[1] * (pos[1] - pose_tr[1]) + pose_R[2] * (pos[2] - pose_tr[2]);
         float y_loc = pose_R[3] * (pos[0] - pose_tr[0]) + pose_R[4] * (pos[1] - pose_tr[1]) + pose_R[5] * (pos[2] - pose_tr[2]);
@@ -310,6 +322,7 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
         q[2 * i] = front[i] ? y_loc / z_loc : 1e30f;  // behind the camera: never queried by the reference
         q[2 * i + 1] = front[i] ? x_loc / z_loc : 1e30f;
     }
+    });
     int rc = gpo.query_staged(n, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     stat_obs_queries += n;
@@ -318,7 +331,8 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     std::vector<float> val(gpo.staged_val(), gpo.staged_val() + n), var(gpo.staged_var(), gpo.staged_var() + n);
     float* q2 = q;
     std::fill(q2, q2 + (size_t)12 * n, 1e30f);
-    for (int i = 0; i < n; ++i) {
+    pool().parallel_for(n, [&](int lo_, int hi_) {
+    for (int i = lo_; i < hi_; ++i) {
         if (!front[i]) continue;
         if (var[i] > setting.obs_var_thre) continue;
         float x_loc = loc[i][0], y_loc = loc[i][1], z_loc = loc[i][2];
@@ -359,6 +373,7 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
             q2[(size_t)12 * i + 2 * k + 1] = X / Z;
         }
     }
+    });
     rc = gpo.query_staged(6 * n, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
     pval.assign(gpo.staged_val(), gpo.staged_val() + (size_t)6 * n);
@@ -366,9 +381,10 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     stat_obs_queries += 6 * (long)n;
 }
 
-// Stage 3 for one point: fusion + tree mutation, in the reference's order.  :410-566
-void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, const float* pvar) {
-    if (!s.go) return;
+// Stage 3 for one point: the fusion arithmetic (pure) ...  :410-566
+GPisMap3::Impl::ReevalOut GPisMap3::Impl::reeval_math(const FlatPoint<3>& nd, const Stage2& s, const float* pval, const float* pvar) const {
+    ReevalOut out;
+    if (!s.go) return out;
     const float w = (float)(1.0 / 6.0);
     const float delx = setting.delx;
     static const float pert[3][6] = {{1, -1, 0, 0, 0, 0}, {0, 0, 1, -1, 0, 0}, {0, 0, 0, 0, 1, -1}};
@@ -388,17 +404,17 @@ void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, c
         r0_sqr_sum += r0 * r0;
         r0_mean += w * r0;
     }
-    if (var > setting.obs_var_thre) return;
+    if (var > setting.obs_var_thre) return out;
 
-    FlatPoint<3> nd = tree.pts[pid];  // copy: the point object is replaced below
     const float* pos = nd.pos;
     const float* grad = nd.grad;
     float gl[3] = {(occ[0] - occ[1]) / delx, (occ[2] - occ[3]) / delx, (occ[4] - occ[5]) / delx};
     float norm_g = std::sqrt(gl[0] * gl[0] + gl[1] * gl[1] + gl[2] * gl[2]);
     if ((double)norm_g < 1e-3) {  // uncertainty increased
-        tree.pts[pid].sigx = (float)(2.0 * (double)nd.sigx);
-        tree.pts[pid].sigg = (float)(2.0 * (double)nd.sigg);
-        return;
+        out.kind = 1;
+        out.noise = (float)(2.0 * (double)nd.sigx);
+        out.gnoise = (float)(2.0 * (double)nd.sigg);
+        return out;
     }
     float r_var = (float)((double)r0_sqr_sum / 5.0 - (double)(r0_mean * r0_mean) * 6.0 / 5.0);
     r_var /= delx;
@@ -450,15 +466,31 @@ void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, c
         grad_noise = std::min((float)1.0, std::max(grad_noise * grad_noise_old / grad_noise_sum + dist2, setting.map_noise_param));
         noise = std::max((noise * noise_old / pos_noise_sum + dist2), setting.map_noise_param);
     }
-    tree.remove(tree.root, nd.pos, &activeSet);
-    if ((double)noise > 1.0 && (double)grad_noise > 0.61) return;
-    int np = tree.new_point(pos_new);
+    out.kind = 2;
+    for (int d = 0; d < 3; ++d) { out.pos[d] = pos_new[d]; out.grad[d] = grad_new[d]; }
+    out.noise = noise; out.gnoise = grad_noise;
+    return out;
+}
+
+// ... and the tree mutation, in the reference's order
+void GPisMap3::Impl::reeval_commit(int pid, const ReevalOut& o) {
+    if (o.kind == 0) return;
+    if (o.kind == 1) { tree.pts[pid].sigx = o.noise; tree.pts[pid].sigg = o.gnoise; return; }
+    float old_pos[3] = {tree.pts[pid].pos[0], tree.pts[pid].pos[1], tree.pts[pid].pos[2]};   // copy: the point object is replaced below
+    tree.remove(tree.root, old_pos, &activeSet);
+    if ((double)o.noise > 1.0 && (double)o.gnoise > 0.61) return;
+    int np = tree.new_point(o.pos);
     T3::InsSet ins;
     if (try_insert(np, ins) != 2) return;
     FlatPoint<3>& p = tree.pts[np];
-    p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
-    for (int d = 0; d < 3; ++d) p.grad[d] = grad_new[d];
+    p.val = -setting.fbias; p.sigx = o.noise; p.sigg = o.gnoise; p.type = 1;
+    for (int d = 0; d < 3; ++d) p.grad[d] = o.grad[d];
     ins.for_each([&](int c) { activeSet.insert(c); });
+}
+
+void GPisMap3::Impl::reeval_apply(int pid, const Stage2& s, const float* pval, const float* pvar) {
+    const FlatPoint<3> nd = tree.pts[pid];
+    reeval_commit(pid, reeval_math(nd, s, pval, pvar));
 }
 
 // ------------------------------------------------------------ updateMapPoints ----
@@ -504,6 +536,13 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
     launch_pixel_batch();      // the new-pixel batch runs on the device while the host replays the re-evaluation below
     std::vector<int> slot(tree.pts.size(), -1);
     for (size_t i = 0; i < ids.size(); ++i) slot[ids[i]] = (int)i;
+    // the fusion arithmetic of every point of the batch on the host threads (a point's outcome depends on its own state only,
+    // and no commit below touches another stored point's data); the tree replay then applies the outcomes in order
+    std::vector<ReevalOut> outs(ids.size());
+    pool().parallel_for((int)ids.size(), [&](int lo, int hi) {
+        for (int i = lo; i < hi; ++i) outs[i] = reeval_math(tree.pts[ids[i]], st[i], &pval[(size_t)6 * i], &pvar[(size_t)6 * i]);
+    });
+    ulap("reEvalPoints: fusion arithmetic");
 
     // replay in the reference's order; node lists are fetched lazily per cluster (:308-311)
     std::vector<int> nodes, late;
@@ -518,8 +557,7 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
         size_t li = 0;
         for (int pid : nodes) {
             if (pid < (int)slot.size() && slot[pid] >= 0) {
-                int i = slot[pid];
-                reeval_apply(pid, st[i], &pval[(size_t)6 * i], &pvar[(size_t)6 * i]);
+                reeval_commit(pid, outs[slot[pid]]);
             } else {
                 reeval_apply(pid, lst[li], &lval[6 * li], &lvar[6 * li]);
                 ++li;

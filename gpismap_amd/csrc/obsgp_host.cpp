@@ -1,7 +1,9 @@
 // Host side of the device ObsGP: partition tables (reference ObsGP.cpp:204-265 for
 // the 2-D tiling, :85-143 for the 1-D groups), buffer management, H2D/D2H.
+#include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <set>
 #include <vector>
 #include <algorithm>
@@ -20,6 +22,8 @@ struct DevPool {
     std::multimap<size_t, char*> free_size_;       // the same blocks by size (best fit)
     std::map<void*, size_t> live_;
     std::vector<void*> chunks_;
+    std::vector<size_t> chunk_sizes_;
+    int device = -1;                               // device the pool was created on (its chunks return to that device's cache)
     std::set<char*> chunk_base_;                   // blocks never merge across two hipMalloc regions
     size_t bytes = 0;
     void drop_free(char* a, size_t sz) {
@@ -29,21 +33,53 @@ struct DevPool {
     }
     void add_free(char* a, size_t sz) { free_addr_[a] = sz; free_size_.insert({sz, a}); }
 };
-DevPool* pool_create() { return new DevPool(); }
+// Standard-size chunks of destroyed pools are kept per device for the next pool of the process (a 512 MiB hipMalloc
+// costs milliseconds -- a map that is reset / re-created per sequence paid for its whole pool again, in the middle of its
+// first frames); bounded by GPIS_POOL_CACHE_GB (default 16, 0 = give everything back at once).
+namespace {
+constexpr size_t kPoolChunk = (size_t)512 << 20;
+std::mutex g_chunk_mu;
+std::map<int, std::vector<void*>> g_chunk_cache;     // device -> free standard-size chunks
+size_t chunk_cache_limit() {
+    static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 16.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
+    return lim;
+}
+void* chunk_cache_take() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_chunk_mu);
+    auto it = g_chunk_cache.find(dev);
+    if (it == g_chunk_cache.end() || it->second.empty()) return nullptr;
+    void* c = it->second.back(); it->second.pop_back();
+    return c;
+}
+bool chunk_cache_put(int dev, void* c) {
+    std::lock_guard<std::mutex> lk(g_chunk_mu);
+    auto& v = g_chunk_cache[dev];
+    if (v.size() >= chunk_cache_limit()) return false;
+    v.push_back(c);
+    return true;
+}
+}  // namespace
+DevPool* pool_create() { DevPool* p = new DevPool(); if (hipGetDevice(&p->device) != hipSuccess) p->device = -1; return p; }
 void pool_destroy(DevPool* p) {
     if (!p) return;
-    for (void* c : p->chunks_) (void)hipFree(c);
+    for (size_t i = 0; i < p->chunks_.size(); ++i) {
+        void* c = p->chunks_[i];
+        if (!(p->chunk_sizes_[i] == kPoolChunk && p->device >= 0 && chunk_cache_put(p->device, c))) (void)hipFree(c);
+    }
     delete p;
 }
 void* pool_alloc(DevPool* p, size_t bytes) {
-    constexpr size_t kGran = 4u << 10, kMinSplit = 64u << 10, kChunk = (size_t)512 << 20;
+    constexpr size_t kGran = 4u << 10, kMinSplit = 64u << 10, kChunk = kPoolChunk;
     size_t c = ((bytes ? bytes : 1) + kGran - 1) / kGran * kGran;
     auto it = p->free_size_.lower_bound(c);
     if (it == p->free_size_.end()) {
         const size_t chunk = std::max(c, kChunk);
-        void* base = nullptr;
-        if (hipMalloc(&base, chunk) != hipSuccess) return nullptr;
+        void* base = (chunk == kChunk) ? chunk_cache_take() : nullptr;
+        if (!base && hipMalloc(&base, chunk) != hipSuccess) return nullptr;
         p->chunks_.push_back(base);
+        p->chunk_sizes_.push_back(chunk);
         p->chunk_base_.insert((char*)base);
         p->bytes += chunk;
         p->add_free((char*)base, chunk);
