@@ -202,7 +202,8 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         }
     };
     auto gen_tile = [&](int c, int qs, float* tbuf) {
-#ifdef K4_ABL_NOGEN      // (timing ablation only: wrong results)
+#ifdef K4_ABL_NOGEN      // (timing ablation only: wrong results.  CAUTION: the B tiles then hold constants, the matrix pipe draws less
+                         // power and the chip clocks higher -- most of the 8 % this "saves" is DVFS, not generation time: NOTEBOOK.md)
         return;
 #endif
         const int r0 = c * 32, r1 = min(K, r0 + 32) - 1;

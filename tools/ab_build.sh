@@ -5,7 +5,7 @@ set -e
 name=$1; flags=$2; shift 2
 cd "$(dirname "$0")/../gpismap_amd/csrc"
 make -s -j8
-mkdir -p /tmp/ab_$name
+mkdir -p /tmp/ab_$name ../../tools/ab
 objs=""
 for o in *.o; do
   base=${o%.o}; keep=1
