@@ -212,6 +212,29 @@ public:
         return res;
     }
 
+    // remove() started at the cached cluster cell when p lies well inside it (walk_start): every ancestor of that cell
+    // contains p away from its splitting planes, so the root walk would have descended exactly this chain through
+    // only_child(); what the recursion does on its way back up -- collapse a node whose children are all empty leaves --
+    // is done for the ancestors explicitly.  Same return value, same tree, same set.
+    bool remove_cached(const float* p, Set* set) {
+        const int c = walk_start(p);
+        if (c == root || c < 0) return remove(root, p, set);
+        if (!remove(c, p, set)) return false;
+        for (int a = nodes[c].par; a >= 0; a = nodes[a].par) {
+            bool all = true;
+            for (int i = 0; i < NC && all; ++i) all = empty_leaf(nodes[a].ch[i]);
+            if (!all) continue;
+            for (int i = 0; i < NC; ++i) {
+                if (set) set->erase(nodes[a].ch[i]);
+                free_subtree(nodes[a].ch[i]);
+                nodes[a].ch[i] = -1;
+            }
+            nodes[a].leaf = true;
+            last_cell = -1;          // (the cached cell was one of the freed children or lies below one)
+        }
+        return true;
+    }
+
     void query_range(int n, const float* c, float h, std::vector<int>& out) const {  // octree.cpp:777-804
         float lo[DIM], hi[DIM];
         for (int d = 0; d < DIM; ++d) { lo[d] = c[d] - h; hi[d] = c[d] + h; }

@@ -477,7 +477,7 @@ void GPisMap3::Impl::reeval_commit(int pid, const ReevalOut& o) {
     if (o.kind == 0) return;
     if (o.kind == 1) { tree.pts[pid].sigx = o.noise; tree.pts[pid].sigg = o.gnoise; return; }
     float old_pos[3] = {tree.pts[pid].pos[0], tree.pts[pid].pos[1], tree.pts[pid].pos[2]};   // copy: the point object is replaced below
-    tree.remove(tree.root, old_pos, &activeSet);
+    tree.remove_cached(old_pos, &activeSet);
     if ((double)o.noise > 1.0 && (double)o.gnoise > 0.61) return;
     int np = tree.new_point(o.pos);
     T3::InsSet ins;

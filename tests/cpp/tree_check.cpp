@@ -85,7 +85,11 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
             typename FT::Set fset;
             typename orc::Tree<DIM>::Set oset;
             bool with_set = rng() & 1;
-            bool fr = ft.remove(ft.root, p, with_set ? &fset : nullptr);
+            // half of the removals through the cached-cell walk the map's replay uses (primed by a lookup of the same point,
+            // as the replay's previous insert does), half from the root
+            const bool cached = (rng() & 1) != 0;
+            if (cached && (rng() & 1)) (void)ft.is_not_new(ft.root, p);
+            bool fr = cached ? ft.remove_cached(p, with_set ? &fset : nullptr) : ft.remove(ft.root, p, with_set ? &fset : nullptr);
             auto n = std::make_shared<orc::MapNode<DIM>>(p);
             bool orr = ot->remove(n, with_set ? &oset : nullptr);
             if (fr != orr) { fprintf(stderr, "op %d remove mismatch %d/%d\n", it, fr, orr); ++bad; }

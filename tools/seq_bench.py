@@ -18,7 +18,26 @@ def ms(f, *a):
     t0 = time.perf_counter(); r = f(*a); return (time.perf_counter() - t0) * 1e3, r
 
 
+def gpu_alone():
+    """data/3D through the HIP path ALONE (no CPU oracle running its 256-thread update between the frames): VERDICT r3 asked
+    whether the 12-15 ms update() outliers of the interleaved run are the oracle's doing."""
+    frames = replay.load_bigbird(); grid = replay.demo3_grid()
+    for rep in range(2):
+        gm = gpismap_amd.GPisMap3(frames[0]["cam"])
+        up, te = [], []
+        for i, fr in enumerate(frames):
+            if i:
+                gm.set_camera(fr["cam"])
+            ug, _ = ms(gm.update, fr["depth"], fr["pose"]); tg, _ = ms(gm.test, grid)
+            up.append(ug); te.append(tg)
+        print("3-D GPU alone, pass %d: update ms per frame %s" % (rep + 1, " ".join("%.1f" % v for v in up)))
+        print("                        test ms per frame   %s" % " ".join("%.1f" % v for v in te))
+        print("   update median of frames 2..40 %.1f ms, max %.1f ms; test median %.1f ms" % (float(np.median(up[1:])), max(up[1:]), float(np.median(te[1:]))))
+
+
 def main():
+    if "--gpu-alone" in sys.argv:
+        return gpu_alone()
     frames = replay.load_bigbird(); grid = replay.demo3_grid()
     gm = gpismap_amd.GPisMap3(frames[0]["cam"]); om = oracle_lib.OracleMap3(frames[0]["cam"])
     print("3-D (data/3D, %d frames in the fixture, %d-point demo grid): frame | points | update ms gpu/cpu | test ms gpu/cpu" % (len(frames), grid.shape[0]))

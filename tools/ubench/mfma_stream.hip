@@ -227,7 +227,7 @@ static void runstep_dma(int wgs_per_cu, const float* dA, float* dout, int steps,
 }
 // argv[1] = "random": A tiles and the LDS operand block hold random normals instead of zeros / small constants.  The gfx950
 // clock follows the power budget and matrix-pipe power follows operand toggling: the zero-data numbers are the
-// scheduling ceiling, the random-data numbers the ceiling a real kernel can reach.
+// scheduling ceiling, the random-data numbers the ceiling a real kernel can reach (NOTEBOOK.md, K4).
 static bool g_random = false;
 int main(int argc, char** argv) {
     const int bytes = 1024 * 4096;
