@@ -105,8 +105,8 @@ public:
     bool empty_leaf(int n) const { return nodes[n].leaf && nodes[n].pt < 0; }
 
     // Where a walk for point p may start: the cached cell if p is well inside it, else the root.
-    int walk_start(const float* p) const {
-        const int n = last_cell;
+    int walk_start(const float* p) const { return walk_start_from(last_cell, p); }
+    int walk_start_from(int n, const float* p) const {
         if (n < 0 || !nodes[n].alive) return root;
         const TNode& t = nodes[n];
         for (int d = 0; d < DIM; ++d) {
@@ -163,22 +163,39 @@ public:
         return false;
     }
 
-    bool is_not_new(int n, const float* p) const {  // octree.cpp:431-460
+    bool is_not_new(int n, const float* p) const { return is_not_new_walk(n, p, &last_cell, nullptr); }  // octree.cpp:431-460
+    // cell: where the last cluster-level cell of the walk is noted (the caller's cache); witness: if non-null and the answer
+    // is true, the node whose stored point lies within the minimum distance of p.
+    bool is_not_new_walk(int n, const float* p, int* cell, int* witness) const {
         if (!contains(n, p)) return false;
         for (;;) {
-            if (at_cluster(n)) last_cell = n;
+            if (at_cluster(n)) *cell = n;
             if (empty_leaf(n)) return false;
-            if (nodes[n].pt >= 0 && sqdist(pts[nodes[n].pt].pos, p) < prm.min_half_sq) return true;
+            if (nodes[n].pt >= 0 && sqdist(pts[nodes[n].pt].pos, p) < prm.min_half_sq) { if (witness) *witness = n; return true; }
             if (nodes[n].leaf) return false;
             const int i = only_child(n, p);
             if (i < 0) {  // next to a splitting plane: the reference's loop over all children
-                for (int k = 0; k < NC; ++k) if (is_not_new(nodes[n].ch[k], p)) return true;
+                for (int k = 0; k < NC; ++k) if (is_not_new_walk(nodes[n].ch[k], p, cell, witness)) return true;
                 return false;
             }
             n = nodes[n].ch[i];
             if (!contains(n, p)) return false;
         }
     }
+    // is_not_new() for MANY points against the tree as it stands, from several threads (nothing is written but the caller's
+    // own cache `cell`): answer true comes with its witness (node, point id).  A true answer stays true for as long as that
+    // node still stores that point: points live in leaves only, a leaf's box and the boxes and splitting planes of its
+    // ancestors never change while it is alive, an ancestor never takes a point of its own, point ids are not reused within
+    // an update -- so the walk for p still arrives at the witness and finds the same point at the same distance.  (It stops
+    // being true when an insert subdivides the witness and its point moves into a child that does not contain p: then
+    // nodes[w].pt != id, and the caller asks again.)  A false answer promises nothing: later inserts can make it true.
+    bool is_not_new_frozen(const float* p, int* cell, int* wnode, int* wpt) const {
+        int w = -1;
+        const bool r = is_not_new_walk(walk_start_from(*cell, p), p, cell, &w);
+        *wnode = w; *wpt = r ? nodes[w].pt : -1;
+        return r;
+    }
+    bool witness_holds(int wnode, int wpt) const { return wnode >= 0 && nodes[wnode].alive && nodes[wnode].pt == wpt; }
 
     // octree.cpp:462-508 (set == nullptr: every child visited) / :510-566.  Removes the point
     // stored at position p (distance^2 < 1e-12) and prunes emptied children.

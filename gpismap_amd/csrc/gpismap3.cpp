@@ -121,6 +121,9 @@ struct GPisMap3::Impl {
 
     float u_obs_limit[2] = {0, 0}, v_obs_limit[2] = {0, 0};
     std::vector<float> vu_grid, obs_zinv, obs_valid_u, obs_valid_v, obs_valid_xyzlocal, obs_valid_xyzglobal;
+    std::vector<int> pre_wnode, pre_wpt;   // evalPoints: witnesses of the frozen is_not_new pre-pass
+    std::vector<int> pix_off;              // preprocData: first valid-pixel index of each column range (pix_parts + 1 entries)
+    int pix_parts = 0;
     float pose_tr[3] = {0, 0, 0}, pose_R[9] = {0};
     int obs_numdata = 0;
     float range_obs_max = 0.f;
@@ -222,8 +225,7 @@ struct GPisMap3::Impl {
 // ------------------------------------------------------------------ preprocess ----
 bool GPisMap3::Impl::preprocData(const float* dataz, int N, const std::vector<float>& pose) {  // :125-216
     if (!dataz || N < 1) return false;
-    obs_valid_xyzlocal.clear(); obs_valid_xyzglobal.clear();
-    obs_valid_u.clear(); obs_valid_v.clear(); obs_zinv.clear();
+    obs_numdata = 0; pix_parts = 0;     // (the pixel arrays keep their storage: sizes follow obs_numdata)
     range_obs_max = 0.0f;
     if (pose.size() != 12) return false;
     for (int i = 0; i < 3; ++i) pose_tr[i] = pose[i];
@@ -248,28 +250,58 @@ bool GPisMap3::Impl::preprocData(const float* dataz, int N, const std::vector<fl
         v_obs_limit[0] = -cam.cy / cam.fy;
         v_obs_limit[1] = ((float)row - cam.cy) / cam.fy;
     }
+    // Two passes over column ranges on the host threads: count the valid pixels per range, then every range writes its
+    // pixels at its offset -- the order (columns, then rows) and every value are those of the sequential loop.  The ranges
+    // are kept (pix_off): the query build and the pre-pass of evalPoints() hand each range to the same thread again.
     obs_numdata = 0;
-    for (int n_ = 0; n_ < n; ++n_) {
-        int col = n_ * setting.obs_skip;
-        for (int m_ = 0; m_ < m; ++m_) {
-            int row = m_ * setting.obs_skip;
-            int k = col * cam.height + row;
-            if (k < N && (double)dataz[k] < 4e0 && (double)dataz[k] > 4e-1) {  // isRangeValid :33-36
-                int j = 2 * (m * n_ + m_);
-                float z = dataz[k];
-                if (range_obs_max < z) range_obs_max = z;
-                obs_zinv.push_back((float)(1.0 / (double)z));
-                float u = vu_grid[j + 1], v = vu_grid[j];
-                obs_valid_u.push_back(u); obs_valid_v.push_back(v);
-                float xloc = u * z, yloc = v * z;
-                obs_valid_xyzlocal.push_back(xloc); obs_valid_xyzlocal.push_back(yloc); obs_valid_xyzlocal.push_back(z);
-                obs_valid_xyzglobal.push_back(pose_R[0] * xloc + pose_R[3] * yloc + pose_R[6] * z + pose_tr[0]);
-                obs_valid_xyzglobal.push_back(pose_R[1] * xloc + pose_R[4] * yloc + pose_R[7] * z + pose_tr[1]);
-                obs_valid_xyzglobal.push_back(pose_R[2] * xloc + pose_R[5] * yloc + pose_R[8] * z + pose_tr[2]);
-                ++obs_numdata;
-            } else obs_zinv.push_back(-1.0f);
+    obs_zinv.resize((size_t)n * m);
+    const int parts = std::max(1, std::min(pool().size(), n / 16));
+    pix_parts = parts;
+    pix_off.assign((size_t)parts + 1, 0);
+    std::vector<float> rmax((size_t)parts, 0.f);
+    auto valid = [&](int k) { return k < N && (double)dataz[k] < 4e0 && (double)dataz[k] > 4e-1; };   // isRangeValid :33-36
+    pool().run_parts(parts, [&](int p) {
+        const int c0 = (int)((long long)n * p / parts), c1 = (int)((long long)n * (p + 1) / parts);
+        int cnt = 0;
+        for (int n_ = c0; n_ < c1; ++n_) {
+            const int col = n_ * setting.obs_skip;
+            for (int m_ = 0; m_ < m; ++m_) cnt += valid(col * cam.height + m_ * setting.obs_skip) ? 1 : 0;
         }
-    }
+        pix_off[(size_t)p + 1] = cnt;
+    });
+    for (int p = 0; p < parts; ++p) pix_off[(size_t)p + 1] += pix_off[(size_t)p];
+    const int total = pix_off[(size_t)parts];
+    obs_valid_u.resize((size_t)total); obs_valid_v.resize((size_t)total);
+    obs_valid_xyzlocal.resize((size_t)3 * total); obs_valid_xyzglobal.resize((size_t)3 * total);
+    pool().run_parts(parts, [&](int p) {
+        const int c0 = (int)((long long)n * p / parts), c1 = (int)((long long)n * (p + 1) / parts);
+        size_t o = (size_t)pix_off[(size_t)p];
+        float rm = 0.f;
+        for (int n_ = c0; n_ < c1; ++n_) {
+            const int col = n_ * setting.obs_skip;
+            for (int m_ = 0; m_ < m; ++m_) {
+                const int row = m_ * setting.obs_skip;
+                const int k = col * cam.height + row;
+                if (valid(k)) {
+                    const int j = 2 * (m * n_ + m_);
+                    const float z = dataz[k];
+                    if (rm < z) rm = z;
+                    obs_zinv[(size_t)m * n_ + m_] = (float)(1.0 / (double)z);
+                    const float u = vu_grid[j + 1], v = vu_grid[j];
+                    obs_valid_u[o] = u; obs_valid_v[o] = v;
+                    const float xloc = u * z, yloc = v * z;
+                    obs_valid_xyzlocal[3 * o] = xloc; obs_valid_xyzlocal[3 * o + 1] = yloc; obs_valid_xyzlocal[3 * o + 2] = z;
+                    obs_valid_xyzglobal[3 * o] = pose_R[0] * xloc + pose_R[3] * yloc + pose_R[6] * z + pose_tr[0];
+                    obs_valid_xyzglobal[3 * o + 1] = pose_R[1] * xloc + pose_R[4] * yloc + pose_R[7] * z + pose_tr[1];
+                    obs_valid_xyzglobal[3 * o + 2] = pose_R[2] * xloc + pose_R[5] * yloc + pose_R[8] * z + pose_tr[2];
+                    ++o;
+                } else obs_zinv[(size_t)m * n_ + m_] = -1.0f;
+            }
+        }
+        rmax[(size_t)p] = rm;
+    });
+    for (int p = 0; p < parts; ++p) if (range_obs_max < rmax[(size_t)p]) range_obs_max = rmax[(size_t)p];
+    obs_numdata = total;
     return obs_numdata > 1;
 }
 
@@ -584,18 +616,21 @@ void GPisMap3::Impl::launch_pixel_batch() {
     UpdLap ulap;
     float* q = gpo.stage_qb(7 * n);   // page-locked staging of the ObsGP object: filled in place, answers read in place
     if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
-    for (int k = 0; k < n; ++k) {
-        const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
-        q[(size_t)14 * k] = obs_valid_v[k];
-        q[(size_t)14 * k + 1] = obs_valid_u[k];
-        for (int i = 0; i < 6; ++i) {
-            float X = xl[0] + delx * kPert3[0][i];
-            float Y = xl[1] + delx * kPert3[1][i];
-            float Z = xl[2] + delx * kPert3[2][i];
-            q[(size_t)14 * k + 2 + 2 * i] = Y / Z;
-            q[(size_t)14 * k + 3 + 2 * i] = X / Z;
+    pool().run_parts(std::max(1, pix_parts), [&](int p) {
+        const int k0 = pix_parts ? pix_off[(size_t)p] : 0, k1 = pix_parts ? pix_off[(size_t)p + 1] : n;
+        for (int k = k0; k < k1; ++k) {
+            const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
+            q[(size_t)14 * k] = obs_valid_v[k];
+            q[(size_t)14 * k + 1] = obs_valid_u[k];
+            for (int i = 0; i < 6; ++i) {
+                float X = xl[0] + delx * kPert3[0][i];
+                float Y = xl[1] + delx * kPert3[1][i];
+                float Z = xl[2] + delx * kPert3[2][i];
+                q[(size_t)14 * k + 2 + 2 * i] = Y / Z;
+                q[(size_t)14 * k + 3 + 2 * i] = X / Z;
+            }
         }
-    }
+    });
     ulap("evalPoints: build queries");
     int rc = gpo.query_staged_b_async(7 * n, batch_stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
@@ -611,6 +646,18 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
     launch_pixel_batch();              // (not yet issued when there was nothing to re-evaluate)
     UpdLap ulap;
     if (!batch_inflight) return;       // (launch_pixel_batch reported why)
+    // Nine pixels out of ten end at "not new" because of a point that was in the map before this pass.  Those answers are
+    // taken for all pixels at once against the tree as it stands now (host thread pool; the tree is not touched), each
+    // with its witness (leaf, point id); the ordered pass below accepts a pre-computed "not new" only while the witness
+    // still holds and asks the tree again otherwise (flat_tree.h: is_not_new_frozen).  A pre-computed "new" is never used.
+    // (Round 2's plain pre-filter was not exact: an insert can subdivide the witness leaf -- that is what the check catches.)
+    pre_wnode.resize((size_t)n); pre_wpt.resize((size_t)n);
+    pool().run_parts(std::max(1, pix_parts), [&](int p) {
+        const int k0 = pix_parts ? pix_off[(size_t)p] : 0, k1 = pix_parts ? pix_off[(size_t)p + 1] : n;
+        int cell = -1;
+        for (int k = k0; k < k1; ++k) tree.is_not_new_frozen(&obs_valid_xyzglobal[3 * (size_t)k], &cell, &pre_wnode[k], &pre_wpt[k]);
+    });
+    ulap("evalPoints: frozen pre-pass");
     batch_inflight = false;
     int rc = gpo.wait_b();
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
@@ -628,6 +675,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         if (pr[0] > setting.obs_var_thre) continue;
         // (the reference allocates the node before IsNotNew and discards it when the test says "not new", GPisMap3.cpp:611-623:
         // no side effect, so the nine pixels out of ten that end here never take a point object)
+        if (tree.witness_holds(pre_wnode[k], pre_wpt[k])) continue;
         if (tree.is_not_new_cached(&obs_valid_xyzglobal[3 * (size_t)k])) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
         T3::InsSet ins;

@@ -33,22 +33,29 @@ public:
     void parallel_for(int n, const std::function<void(int, int)>& f, int min_per_thread = 256) {
         const int parts = std::max(1, std::min(nthreads_, n / std::max(1, min_per_thread)));
         if (parts <= 1) { if (n > 0) f(0, n); return; }
+        run_parts(parts, [&](int p) {
+            const int lo = (int)((long long)n * p / parts), hi = (int)((long long)n * (p + 1) / parts);
+            if (hi > lo) f(lo, hi);
+        });
+    }
+    // g(part) for part = 0 .. parts-1 (parts <= size()); part p always runs on the same thread (0 = the caller), so data a
+    // part writes in one call and reads or rewrites in the next stays in that core's cache
+    void run_parts(int parts, const std::function<void(int)>& g) {
+        parts = std::max(1, std::min(parts, nthreads_));
+        if (parts == 1) { g(0); return; }
         {
             std::lock_guard<std::mutex> lk(mu_);
-            fn_ = &f; n_ = n; parts_ = parts; pending_ = parts - 1; ++gen_;
+            fn_ = &g; parts_ = parts; pending_ = parts - 1; ++gen_;
         }
         cv_.notify_all();
-        run_part(0);
+        g(0);
         std::unique_lock<std::mutex> lk(mu_);
         done_.wait(lk, [this] { return pending_ == 0; });
         fn_ = nullptr;
     }
 
 private:
-    void run_part(int p) {
-        const int lo = (int)((long long)n_ * p / parts_), hi = (int)((long long)n_ * (p + 1) / parts_);
-        if (hi > lo) (*fn_)(lo, hi);
-    }
+    void run_part(int p) { (*fn_)(p); }
     void worker(int id) {
         unsigned long long seen = 0;
         for (;;) {
@@ -67,8 +74,8 @@ private:
     std::vector<std::thread> workers_;
     std::mutex mu_;
     std::condition_variable cv_, done_;
-    const std::function<void(int, int)>* fn_ = nullptr;
-    int n_ = 0, parts_ = 1, pending_ = 0;
+    const std::function<void(int)>* fn_ = nullptr;
+    int parts_ = 1, pending_ = 0;
     unsigned long long gen_ = 0;
     bool stop_ = false;
 };

@@ -32,7 +32,31 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
     int bad = 0, inserted = 0, removed = 0, onplane = 0;
     float prev[3] = {0, 0, 0};
     bool have_prev = false;
+    // probes of the frozen pre-pass (evalPoints): "not new" answers taken at one moment with their witnesses; while a witness
+    // holds, the answer must still be what a fresh walk says, whatever was inserted or removed since
+    struct Probe { float p[3]; int wnode, wpt; };
+    std::vector<Probe> probes;
+    int probes_held = 0, probes_lost = 0;
     for (int it = 0; it < nops && !bad; ++it) {
+        if (it % 400 == 0 && !live.empty()) {
+            probes.clear();
+            int cellc = -1;
+            for (int k = 0; k < 96; ++k) {
+                Probe pr{};
+                const auto& q = live[rng() % live.size()];
+                for (int d = 0; d < DIM; ++d) pr.p[d] = q[d] + ((k & 3) == 0 ? 2.0f : 0.6f) * fp.min_half * U(rng);
+                const bool r = ft.is_not_new_frozen(pr.p, &cellc, &pr.wnode, &pr.wpt);
+                if (r != ft.is_not_new(ft.root, pr.p)) { fprintf(stderr, "op %d: frozen and root walks disagree\n", it); ++bad; }
+                if (r) probes.push_back(pr);
+            }
+        } else if (it % 8 == 0) {
+            for (const Probe& pr : probes) {
+                if (ft.witness_holds(pr.wnode, pr.wpt)) {
+                    ++probes_held;
+                    if (!ft.is_not_new(ft.root, pr.p)) { fprintf(stderr, "op %d: witness holds but the walk says new\n", it); ++bad; }
+                } else ++probes_lost;
+            }
+        }
         int kind = rng() % 10;
         if (kind < 7 || live.empty()) {
             float p[3] = {0, 0, 0};
@@ -145,6 +169,7 @@ static int run(unsigned seed, int nops, float spread, bool quiet) {
     }
     std::vector<int> fa;
     ft.all_points(ft.root, fa);
+    if (!quiet) printf("dim %d seed %u: frozen probes checked while their witness held %d, witnesses lost %d\n", DIM, seed, probes_held, probes_lost);
     if (!quiet) printf("dim %d seed %u: %d ops, %d inserted, %d removed, %d on-plane candidates, %zu stored, %s\n", DIM, seed, nops, inserted,
                        removed, onplane, fa.size(), bad ? "MISMATCH" : "identical");
     delete ot;
