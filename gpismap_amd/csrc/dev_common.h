@@ -37,6 +37,7 @@ namespace gpis {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 // ---- reference-exact scalar kernels (device) --------------------------------
 __device__ __forceinline__ float d_ou_k(float r, float a) { return (float)exp((double)(-a * r)); }

@@ -669,6 +669,9 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
     // exact -- an insert can split a node and move its stored point into a child that no longer contains a later pixel, which
     // flips that pixel's is_not_new() from true to false (29 996 instead of 30 012 points after frame 2).  The pass stays in order.
 
+#ifdef GPIS_INSTRUMENT
+    long dbg_full = 0, dbg_lost = 0, dbg_ins = 0;
+#endif
     for (int k = 0; k < n; ++k) {
         const float* pv = &val[(size_t)7 * k];
         const float* pr = &var[(size_t)7 * k];
@@ -676,10 +679,16 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         // (the reference allocates the node before IsNotNew and discards it when the test says "not new", GPisMap3.cpp:611-623:
         // no side effect, so the nine pixels out of ten that end here never take a point object)
         if (tree.witness_holds(pre_wnode[k], pre_wpt[k])) continue;
+#ifdef GPIS_INSTRUMENT
+        ++dbg_full; if (pre_wnode[k] >= 0) ++dbg_lost;
+#endif
         if (tree.is_not_new_cached(&obs_valid_xyzglobal[3 * (size_t)k])) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
         T3::InsSet ins;
         if (try_insert(pid, ins) != 2) continue;
+#ifdef GPIS_INSTRUMENT
+        ++dbg_ins;
+#endif
         const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
         float occ[6] = {-1, -1, -1, -1, -1, -1};
         float occ_mean = 0.f;
@@ -718,6 +727,9 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         ins.for_each([&](int c) { activeSet.insert(c); });
     }
     ulap("evalPoints: insert pass");
+#ifdef GPIS_INSTRUMENT
+    fprintf(stderr, "[upd]   pixels %d: asked the tree %ld (witness lost %ld), stored %ld\n", n, dbg_full, dbg_lost, dbg_ins);
+#endif
 }
 
 // -------------------------------------------------------------------- updateGPs ----

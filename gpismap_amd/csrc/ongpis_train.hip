@@ -574,6 +574,14 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
         }
     };
+    // What another workgroup reads inside this launch -- the re-tiled rows (Lt) and the factored diagonal block -- is stored
+    // WRITE-THROUGH (16-byte sc1 stores: the bytes leave this XCD's L2 at once), so a hand-over is "every storing wavefront
+    // drains its stores (vmcnt(0)), barrier, one lane moves the counter": no release fence, which would write back whatever
+    // else this XCD's L2 holds dirty at that moment (2-6 us per hand-over, twice per block column, on the serial path of the
+    // cluster).  The diagonal block travels as one 4 KB piece through the (j, j) slot of Zt -- K3b fills every Zt slot before it
+    // reads it, so the slot is free here.  The column-major factor L is read by the back-substitution only (after `alldone`,
+    // which keeps its release fence).
+    const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
     // one lane polls a device-scope flag, then the workgroup acquires; false: the wait expired or a partner aborted
     int nwait = 0;
     auto wait_flag = [&](int* f, int v) -> bool {
@@ -619,6 +627,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             }
         }
     };
+    f32x16 dnext;          // wavefront 0: the accumulated diagonal block of the next pivot row, when this workgroup owns it
+    int dnext_row = -1;
     auto finish = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
         diag_solve32<true>(acc, Lc, h);
 #pragma unroll
@@ -629,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
         float tq[16];      // -L(bi, j) in A-operand order
-        float4* dst = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(bi, j) * 1024);
+        const int tbase = tri_index(bi, j) * 4096;
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg) {
             float4 q;
@@ -637,7 +647,8 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
             q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
             q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
-            dst[gg * 64 + lane] = q;
+            u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+            __builtin_amdgcn_raw_buffer_store_b128(qu, Trs, Tvoff, tbase + gg * 1024, 16);      // (aux 16 = sc1: write-through)
             tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
         }
         __builtin_amdgcn_wave_barrier();
@@ -647,13 +658,18 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
 #pragma unroll
             for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
+            if (bi == j + 1) {
+                // the next pivot block, complete with this update: it stays in the registers of the wavefront that factorises
+                // it in the next step (row j + 1 is always the first look-ahead row of its owner's wavefront 0)
+                dnext = dacc; dnext_row = bi;
+            } else {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
+                for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
+            }
         }
     };
-    auto publish = [&](int* f, int v) {      // one lane: this workgroup's stores (ordered by the barrier before) become visible, then the counter moves
+    auto publish = [&](int* f, int v) {      // one lane moves the counter; the write-through stores it announces were drained by their wavefronts before
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // (an abort mark of a partner must survive: only move the counter forward from a non-negative value)
             if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
@@ -675,6 +691,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
         const int bi0 = first + wave * G, bi1 = bi0 + NW * G;       // the two look-ahead rows of this wavefront
         f32x16 acc0, acc1;
         if (owner) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its write-through tile stores of the previous steps have left
             __syncthreads();           // this workgroup's stores of the previous steps (tiles of row j, its diagonal updates)
             publish(rowtiles, j + 1);
             if (wave != 0) {
@@ -685,8 +702,11 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 // the vector L1 is not refreshed by stores)
                 // (aux 16 = sc1: the device-scope load of the agent-relaxed atomic this replaces -- served by L2, not the CU's L1)
                 f32x16 t;      // the accumulated diagonal block: lane = row, 16 of the 32 columns per lane half
+                if (dnext_row == j) t = dnext;      // (kept by this wavefront at the end of the previous step)
+                else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
+                    for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
+                }
                 if (pw == 32) {
                     // micro-blocked factorisation in accumulator layout (tile_solve.h: same operations in the same order as
                     // factor32_inreg, the trailing updates of a micro-block as four matrix instructions): about half the cycles
@@ -730,9 +750,23 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                         }
                     }
                 }
+                // The padded block as the partners will use it (Lc), 4 KB write-through into the (j, j) slot of Zt.  It was written
+                // by this wavefront alone: it hands the block over itself, at once -- the partners' solves of column j need not
+                // wait for the other seven wavefronts' product chains (the barrier below).
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                {
+                    const int zbase = tri_index(j, j) * 4096;
+#pragma unroll
+                    for (int gg = 0; gg < 4; ++gg) {
+                        const float4 q = reinterpret_cast<const float4*>(Lc)[gg * 64 + lane];
+                        u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(qu, Zrs, Tvoff, zbase + gg * 1024, 16);
+                    }
+                }
+                if (!(inject && j == 1)) publish(rowready, j + 1);
             }
-            __syncthreads();           // L_jj stored and in Lc; the other wavefronts' chains are accumulated
-            if (!(inject && j == 1)) publish(rowready, j + 1);
+            __syncthreads();           // L_jj in Lc for this workgroup's own solves; the other wavefronts' chains are accumulated
             if (wave == 0) {
                 // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it).  After
                 // the hand-over: nobody in this kernel reads it.
@@ -752,11 +786,10 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             if (bi0 < nbr) chain(acc0, bi0, j);
             if (bi1 < nbr) chain(acc1, bi1, j);
             if (!wait_flag(rowready, j + 1)) return;
-            // non-owners rebuild the padded diagonal factor from the published block
-            for (int idx = tid; idx < 1024; idx += 512) {
-                const int c = idx >> 5, r = idx & 31;
-                const float v = L[(size_t)(j * 32 + r) + (size_t)(j * 32 + c) * ld];
-                Lc[c * 32 + r] = (pw == 32 || (r < pw && c < pw)) ? v : (r == c ? 1.f : 0.f);
+            // non-owners copy the published (padded) diagonal factor
+            if (tid < 256) {
+                auto q = __builtin_amdgcn_raw_buffer_load_b128(Zrs, tid * 16, tri_index(j, j) * 4096, 16);
+                reinterpret_cast<float4*>(Lc)[tid] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
             }
             __syncthreads();
         }
