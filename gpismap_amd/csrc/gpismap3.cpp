@@ -121,7 +121,11 @@ struct GPisMap3::Impl {
 
     float u_obs_limit[2] = {0, 0}, v_obs_limit[2] = {0, 0};
     std::vector<float> vu_grid, obs_zinv, obs_valid_u, obs_valid_v, obs_valid_xyzlocal, obs_valid_xyzglobal;
+    struct NewPoint { bool keep = false; float grad[3] = {0, 0, 0}; float noise = 0.f, gnoise = 0.f; };
+    NewPoint pixel_point(const float* pv, const float* pr, const float* xl) const;
     std::vector<int> pre_wnode, pre_wpt;   // evalPoints: witnesses of the frozen is_not_new pre-pass
+    std::vector<NewPoint> pre_new;         // ... and the data of the pixels that were new as of the pre-pass
+    std::vector<float> mirror_soa;         // updateGPs: host image of the point mirror (9 SoA rows)
     std::vector<int> pix_off;              // preprocData: first valid-pixel index of each column range (pix_parts + 1 entries)
     int pix_parts = 0;
     float pose_tr[3] = {0, 0, 0}, pose_R[9] = {0};
@@ -637,27 +641,52 @@ void GPisMap3::Impl::launch_pixel_batch() {
     batch_inflight = true;
 }
 
-void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
-    if (!has_tree || obs_numdata < 1) return;
+// The data of a new surface point from its pixel's seven ObsGP answers (GPisMap3.cpp:624-690): pure per pixel.
+GPisMap3::Impl::NewPoint GPisMap3::Impl::pixel_point(const float* pv, const float* pr, const float* xl) const {
+    NewPoint o;
     const float w = (float)(1.0 / 6.0);
     const float delx = setting.delx;
-    const int n = obs_numdata;
     const float (&pert)[3][6] = kPert3;
+    float occ[6] = {-1, -1, -1, -1, -1, -1};
+    float occ_mean = 0.f;
+    float v = pr[0];
+    for (int i = 0; i < 6; ++i) {
+        float Z = xl[2] + delx * pert[2][i];
+        v = pr[1 + i];
+        if (v > setting.obs_var_thre) break;
+        occ[i] = occ_test((float)(1.0 / (double)Z), pv[1 + i], (float)((double)Z * 30.0));
+        occ_mean += w * occ[i];
+    }
+    if (v > setting.obs_var_thre) return o;      // keep == false: the point is taken out of the tree again
+    o.keep = true;
+    float noise = 100.0f, grad_noise = 1.00f;
+    float g[3] = {(occ[0] - occ[1]) / delx, (occ[2] - occ[3]) / delx, (occ[4] - occ[5]) / delx};
+    float norm_grad = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
+    if ((double)norm_grad > 1e-6) {
+        norm_grad = std::sqrt(norm_grad);
+        float gx = g[0] / norm_grad, gy = g[1] / norm_grad, gz = g[2] / norm_grad;
+        g[0] = pose_R[0] * gx + pose_R[3] * gy + pose_R[6] * gz;
+        g[1] = pose_R[1] * gx + pose_R[4] * gy + pose_R[7] * gz;
+        g[2] = pose_R[2] * gx + pose_R[5] * gy + pose_R[8] * gz;
+        float dist = std::sqrt(xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
+        noise = setting.min_position_noise * saturate(dist, 1.0f, noise);
+        grad_noise = saturate(std::fabs(occ_mean), setting.min_grad_noise, grad_noise);
+        float view_ang = std::max(-(xl[0] * gx + xl[1] * gy + xl[2] * gz) / dist, (float)1e-1);
+        float view_ang2 = view_ang * view_ang;
+        float view_noise = (float)((double)setting.min_position_noise * ((1.0 - (double)view_ang2) / (double)view_ang2));
+        noise += view_noise;
+    }
+    o.noise = noise; o.gnoise = grad_noise;
+    for (int d = 0; d < 3; ++d) o.grad[d] = g[d];
+    return o;
+}
+
+void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
+    if (!has_tree || obs_numdata < 1) return;
+    const int n = obs_numdata;
     launch_pixel_batch();              // (not yet issued when there was nothing to re-evaluate)
     UpdLap ulap;
     if (!batch_inflight) return;       // (launch_pixel_batch reported why)
-    // Nine pixels out of ten end at "not new" because of a point that was in the map before this pass.  Those answers are
-    // taken for all pixels at once against the tree as it stands now (host thread pool; the tree is not touched), each
-    // with its witness (leaf, point id); the ordered pass below accepts a pre-computed "not new" only while the witness
-    // still holds and asks the tree again otherwise (flat_tree.h: is_not_new_frozen).  A pre-computed "new" is never used.
-    // (Round 2's plain pre-filter was not exact: an insert can subdivide the witness leaf -- that is what the check catches.)
-    pre_wnode.resize((size_t)n); pre_wpt.resize((size_t)n);
-    pool().run_parts(std::max(1, pix_parts), [&](int p) {
-        const int k0 = pix_parts ? pix_off[(size_t)p] : 0, k1 = pix_parts ? pix_off[(size_t)p + 1] : n;
-        int cell = -1;
-        for (int k = k0; k < k1; ++k) tree.is_not_new_frozen(&obs_valid_xyzglobal[3 * (size_t)k], &cell, &pre_wnode[k], &pre_wpt[k]);
-    });
-    ulap("evalPoints: frozen pre-pass");
     batch_inflight = false;
     int rc = gpo.wait_b();
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return; }
@@ -665,22 +694,38 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
     const float* val = gpo.staged_val_b();
     const float* var = gpo.staged_var_b();
     ulap("evalPoints: K2 batch");
-    // NB (measured, round 2): pre-filtering the pixels with is_not_new() against the tree as it stands before this pass is NOT
-    // exact -- an insert can split a node and move its stored point into a child that no longer contains a later pixel, which
-    // flips that pixel's is_not_new() from true to false (29 996 instead of 30 012 points after frame 2).  The pass stays in order.
+    // Pre-pass over all pixels on the host threads (column ranges of preprocData; the tree is not touched):
+    //  * the variance gate of the centre query (witness node kGated);
+    //  * "not new" against the tree as it stands now, each answer with its witness (leaf, point id): nine pixels out of ten
+    //    end there because of a point that was in the map before this pass.  The ordered pass below accepts such an answer
+    //    only while the witness still holds and asks the tree again otherwise (flat_tree.h: is_not_new_frozen) -- round 2's
+    //    plain pre-filter was not exact, because an insert can subdivide the witness leaf;
+    //  * for the pixels that are new as of now, the data of the point they would become (pure arithmetic of the pixel's
+    //    seven answers).  A pre-computed "new" itself is never trusted: the ordered pass asks the tree.
+    constexpr int kGated = -2;
+    pre_wnode.resize((size_t)n); pre_wpt.resize((size_t)n); pre_new.resize((size_t)n);
+    pool().run_parts(std::max(1, pix_parts), [&](int p) {
+        const int k0 = pix_parts ? pix_off[(size_t)p] : 0, k1 = pix_parts ? pix_off[(size_t)p + 1] : n;
+        int cell = -1;
+        for (int k = k0; k < k1; ++k) {
+            if (var[(size_t)7 * k] > setting.obs_var_thre) { pre_wnode[k] = kGated; continue; }
+            if (!tree.is_not_new_frozen(&obs_valid_xyzglobal[3 * (size_t)k], &cell, &pre_wnode[k], &pre_wpt[k]))
+                pre_new[k] = pixel_point(&val[(size_t)7 * k], &var[(size_t)7 * k], &obs_valid_xyzlocal[3 * (size_t)k]);
+        }
+    });
+    ulap("evalPoints: frozen pre-pass");
 
 #ifdef GPIS_INSTRUMENT
     long dbg_full = 0, dbg_lost = 0, dbg_ins = 0;
 #endif
     for (int k = 0; k < n; ++k) {
-        const float* pv = &val[(size_t)7 * k];
-        const float* pr = &var[(size_t)7 * k];
-        if (pr[0] > setting.obs_var_thre) continue;
+        const int w = pre_wnode[k];
+        if (w == kGated) continue;
         // (the reference allocates the node before IsNotNew and discards it when the test says "not new", GPisMap3.cpp:611-623:
         // no side effect, so the nine pixels out of ten that end here never take a point object)
-        if (tree.witness_holds(pre_wnode[k], pre_wpt[k])) continue;
+        if (tree.witness_holds(w, pre_wpt[k])) continue;
 #ifdef GPIS_INSTRUMENT
-        ++dbg_full; if (pre_wnode[k] >= 0) ++dbg_lost;
+        ++dbg_full; if (w >= 0) ++dbg_lost;
 #endif
         if (tree.is_not_new_cached(&obs_valid_xyzglobal[3 * (size_t)k])) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
@@ -689,41 +734,15 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
 #ifdef GPIS_INSTRUMENT
         ++dbg_ins;
 #endif
-        const float* xl = &obs_valid_xyzlocal[3 * (size_t)k];
-        float occ[6] = {-1, -1, -1, -1, -1, -1};
-        float occ_mean = 0.f;
-        float v = pr[0];
-        for (int i = 0; i < 6; ++i) {
-            float Z = xl[2] + delx * pert[2][i];
-            v = pr[1 + i];
-            if (v > setting.obs_var_thre) break;
-            occ[i] = occ_test((float)(1.0 / (double)Z), pv[1 + i], (float)((double)Z * 30.0));
-            occ_mean += w * occ[i];
-        }
-        if (v > setting.obs_var_thre) {
+        // (a pixel whose witness was lost on the way has no pre-computed data)
+        const NewPoint np = (w < 0) ? pre_new[k] : pixel_point(&val[(size_t)7 * k], &var[(size_t)7 * k], &obs_valid_xyzlocal[3 * (size_t)k]);
+        if (!np.keep) {
             tree.remove(tree.root, tree.pts[pid].pos, nullptr);
             continue;
         }
-        float noise = 100.0f, grad_noise = 1.00f;
-        float g[3] = {(occ[0] - occ[1]) / delx, (occ[2] - occ[3]) / delx, (occ[4] - occ[5]) / delx};
-        float norm_grad = g[0] * g[0] + g[1] * g[1] + g[2] * g[2];
-        if ((double)norm_grad > 1e-6) {
-            norm_grad = std::sqrt(norm_grad);
-            float gx = g[0] / norm_grad, gy = g[1] / norm_grad, gz = g[2] / norm_grad;
-            g[0] = pose_R[0] * gx + pose_R[3] * gy + pose_R[6] * gz;
-            g[1] = pose_R[1] * gx + pose_R[4] * gy + pose_R[7] * gz;
-            g[2] = pose_R[2] * gx + pose_R[5] * gy + pose_R[8] * gz;
-            float dist = std::sqrt(xl[0] * xl[0] + xl[1] * xl[1] + xl[2] * xl[2]);
-            noise = setting.min_position_noise * saturate(dist, 1.0f, noise);
-            grad_noise = saturate(std::fabs(occ_mean), setting.min_grad_noise, grad_noise);
-            float view_ang = std::max(-(xl[0] * gx + xl[1] * gy + xl[2] * gz) / dist, (float)1e-1);
-            float view_ang2 = view_ang * view_ang;
-            float view_noise = (float)((double)setting.min_position_noise * ((1.0 - (double)view_ang2) / (double)view_ang2));
-            noise += view_noise;
-        }
         FlatPoint<3>& p = tree.pts[pid];
-        p.val = -setting.fbias; p.sigx = noise; p.sigg = grad_noise; p.type = 1;
-        for (int d = 0; d < 3; ++d) p.grad[d] = g[d];
+        p.val = -setting.fbias; p.sigx = np.noise; p.sigg = np.gnoise; p.type = 1;
+        for (int d = 0; d < 3; ++d) p.grad[d] = np.grad[d];
         ins.for_each([&](int c) { activeSet.insert(c); });
     }
     ulap("evalPoints: insert pass");
@@ -761,13 +780,16 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         // mirror of the map points in HBM: 9 SoA rows indexed by point id (the range gather below reads the positions)
         {
             size_t np = tree.pts.size();
-            std::vector<float> soa(9 * np, 0.f);
-            for (size_t i = 0; i < np; ++i) {
-                const FlatPoint<3>& p = tree.pts[i];
-                for (int d = 0; d < 3; ++d) { soa[d * np + i] = p.pos[d]; soa[(3 + d) * np + i] = p.grad[d]; }
-                soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
-            }
-            rc = store.upload_points(soa.data(), (int)np, train_stream);
+            mirror_soa.resize(9 * np);
+            float* soa = mirror_soa.data();
+            pool().parallel_for((int)np, [&](int lo, int hi) {
+                for (size_t i = (size_t)lo; i < (size_t)hi; ++i) {
+                    const FlatPoint<3>& p = tree.pts[i];
+                    for (int d = 0; d < 3; ++d) { soa[d * np + i] = p.pos[d]; soa[(3 + d) * np + i] = p.grad[d]; }
+                    soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
+                }
+            }, 4096);
+            rc = store.upload_points(soa, (int)np, train_stream);
             ulap("updateGPs: point mirror");
         }
         if (rc == GPIS_OK && device_gather) {
