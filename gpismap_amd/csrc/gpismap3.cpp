@@ -171,7 +171,8 @@ struct GPisMap3::Impl {
              (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
              (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess) &&
              (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
-        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) pipeline = atoi(e) != 0;
+        if (const char* e = getenv("GPIS_PIPELINE_RESERVE_CUS")) pipeline_reserve = std::max(0, atoi(e));
+        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) if (ok && atoi(e) != 0) set_pipeline(true);
         if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
         if (const char* e = getenv("GPIS_EAGER_INVERSE")) if (atoi(e) != 0) store.lazy_inverse = false;
         store.trim_scratch = true;     // a cluster keeps only what prediction reads once its inverse exists (GPIS_KEEP_FACTORS=1: keep all)
@@ -188,6 +189,25 @@ struct GPisMap3::Impl {
         if (stream) (void)hipStreamDestroy(stream);
         if (train_stream) (void)hipStreamDestroy(train_stream);
         if (batch_stream) (void)hipStreamDestroy(batch_stream);
+    }
+
+    // Pipelined update: the training of frame f runs beside the host work and the ObsGP batches of frame f + 1.  A factorisation
+    // workgroup holds its CU for milliseconds and nothing pre-empts it, so the training streams are kept off
+    // `pipeline_reserve` CUs (spread evenly over the XCDs): the ObsGP kernels -- highest priority, unmasked -- start at once
+    // there (measured, tools/ubench/cumask_probe.hip: 6 us instead of 2 ms beside a busy unmasked stream).
+    int pipeline_reserve = 32;
+    void set_pipeline(bool on) {
+        (void)store.train_finish();
+        const int want = on ? pipeline_reserve : 0;
+        if (want != store.cu_reserve()) {
+            (void)store.set_cu_reserve(want);
+            hipStream_t ns = nullptr;
+            if (ongpis_make_train_stream(&ns, want) == GPIS_OK && ns) {
+                if (train_stream) { (void)hipStreamSynchronize(train_stream); (void)hipStreamDestroy(train_stream); }
+                train_stream = ns;
+            }
+        }
+        pipeline = on;
     }
 
     void reset() {  // GPisMap3.cpp:99-115
@@ -1325,7 +1345,7 @@ void gpis3_impl_set_pipeline(GPisMap3* g, int on) {
     for (GPisMap3* q : m.peers) gpis3_impl_set_pipeline(q, on);
     DeviceScope ds(m.device);
     m.finish_training();
-    m.pipeline = on != 0;
+    m.set_pipeline(on != 0);
 }
 // join the training in flight and compute the inverses it left to the first prediction; returns the update status
 int gpis3_impl_prepare_test(GPisMap3* g) {

@@ -113,6 +113,11 @@ public:
     // that the host work of the NEXT update() runs beside the factorisations of this one; every other entry point of the
     // store that touches models, points or the training buffers joins first.  false: train_batch() joins before it returns.
     bool defer_finish = false;
+    // CUs the training streams leave alone (hipExtStreamCreateWithCUMask on the side streams; the caller masks its own stream
+    // with ongpis_make_train_stream).  The pipelined map update sets it: the ObsGP queries of the next frame then find free CUs
+    // at once instead of waiting for a factorisation workgroup (milliseconds each) to end.  Changing it joins the training.
+    int set_cu_reserve(int n);
+    int cu_reserve() const { return cu_reserve_; }
     // Lazy inverse (default): training of the K > 256 clusters stops at the factor and alpha; the explicit inverse X = L^-1
     // that prediction multiplies with (K3b) is computed by ensure_inverses() at the FIRST use of the models after a
     // training -- prediction (eval_jobs, the map's test()), packing for the exchange.  A cluster retrained in several
@@ -172,6 +177,7 @@ private:
     hipStream_t pend_stream_ = nullptr;
     std::vector<int> pend_models_;               // slots of the batch in flight
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    int cu_reserve_ = 0;
     hipStream_t s2_ = nullptr, s3_ = nullptr;    // side streams: the three size groups of a training batch run beside each other
     hipEvent_t evf_ = nullptr, evj_ = nullptr, evj3_ = nullptr;   // fork / joins
 };
@@ -207,6 +213,10 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
 int ongpis_coop_capacity();
+// A stream for training kernels: lowest priority; with reserve_cus > 0 restricted to the first (CUs - reserve_cus) bits of the CU
+// mask -- on gfx950 bit i is CU i / 8 of XCD i % 8, so every XCD keeps the same number of CUs and workgroup ids still go round
+// the eight XCDs (tools/ubench/cumask_probe.hip).
+int ongpis_make_train_stream(hipStream_t* s, int reserve_cus);
 // K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs
 void ongpis_launch_inverse(const ClusterModel* d_models, const int* d_jobs, const int* d_work, int nlong, int nmid, int nshort, int* d_ctl, hipStream_t s);
 int ongpis_inverse_short_rows();

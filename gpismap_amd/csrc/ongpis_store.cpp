@@ -53,6 +53,28 @@ void coop_give_back(int dev, int n) {
 OnGPISStore::OnGPISStore(int dim, float scale) : dim_(dim), scale_(scale), pool_(pool_create()) {
 }
 
+int ongpis_make_train_stream(hipStream_t* s, int reserve_cus) {
+    int pr_least = 0, pr_greatest = 0, dev = 0, ncu = 0;
+    GPIS_HIP(hipGetDevice(&dev));
+    GPIS_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
+    GPIS_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (reserve_cus <= 0 || reserve_cus >= ncu) { GPIS_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr_least)); return GPIS_OK; }
+    std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+    for (int i = 0; i < ncu - reserve_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    GPIS_HIP(hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()));
+    return GPIS_OK;
+}
+
+int OnGPISStore::set_cu_reserve(int n) {
+    n = std::max(0, n);
+    if (n == cu_reserve_) return GPIS_OK;
+    const int rc = train_finish();
+    if (s2_) { (void)hipStreamSynchronize(s2_); (void)hipStreamDestroy(s2_); s2_ = nullptr; }
+    if (s3_) { (void)hipStreamSynchronize(s3_); (void)hipStreamDestroy(s3_); s3_ = nullptr; }
+    cu_reserve_ = n;
+    return rc;
+}
+
 OnGPISStore::~OnGPISStore() {
     clear();
     if (h_err_) (void)hipHostFree(h_err_);
@@ -499,6 +521,11 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
     (void)hipGetDevice(&coop_dev);
     const int coop_share = coop_take_all(coop_dev);   // free cooperative workgroups of this device (per-device budget, see above)
     int kCoopMinNb = 32, kCoopMaxWG = coop_share;
+    if (cu_reserve_ > 0) {      // masked streams: fewer CUs can hold cooperative workgroups at once
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, coop_dev) == hipSuccess && ncu > cu_reserve_)
+            kCoopMaxWG = std::min(kCoopMaxWG, std::max(2, (ncu - cu_reserve_) - (ncu - cu_reserve_) / 16));
+    }
     int kCoopGDiv = 900, kCoopGMax = 6;
     int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
@@ -584,10 +611,10 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
     if (lazy) for (int j = 0; j < nsep; ++j) mark_stale(tab[4 * j]);
     if (!s2_) {   // side streams / events of the size groups (created once, outside the timed interval)
         // (lowest priority: in the pipelined map update the ObsGP queries of the next frame run beside these and must not wait)
-        int pr_least = 0, pr_greatest = 0;
-        GPIS_HIP(hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest));
-        GPIS_HIP(hipStreamCreateWithPriority(&s2_, hipStreamNonBlocking, pr_least));
-        GPIS_HIP(hipStreamCreateWithPriority(&s3_, hipStreamNonBlocking, pr_least));
+        if (int src = ongpis_make_train_stream(&s2_, cu_reserve_)) return src;
+        if (int src = ongpis_make_train_stream(&s3_, cu_reserve_)) return src;
+    }
+    if (!evf_) {
         GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
         GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
         GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
