@@ -172,7 +172,12 @@ struct GPisMap3::Impl {
              (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess) &&
              (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
         if (const char* e = getenv("GPIS_PIPELINE_RESERVE_CUS")) pipeline_reserve = std::max(0, atoi(e));
-        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) if (ok && atoi(e) != 0) set_pipeline(true);
+        // update() is pipelined by default: it returns once the frame's training is enqueued; whatever needs the models (the
+        // next training, test(), the getters, gpis3_sync) joins it.  GPIS_PIPELINE_UPDATE=0 / gpis3_set_pipeline(map, 0): every
+        // update() joins its own training before it returns, like the reference's.
+        bool want_pipeline = true;
+        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) want_pipeline = atoi(e) != 0;
+        if (ok && want_pipeline) set_pipeline(true);
         if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
         if (const char* e = getenv("GPIS_EAGER_INVERSE")) if (atoi(e) != 0) store.lazy_inverse = false;
         store.trim_scratch = true;     // a cluster keeps only what prediction reads once its inverse exists (GPIS_KEEP_FACTORS=1: keep all)
@@ -784,11 +789,16 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         for (int c : qs) updateSet.insert(c);
     }
     ulap("updateGPs: neighbour sets");
-    finish_training();          // the previous frame's batch: joined before any model slot is released or allocated
-    ulap("updateGPs: join");
-    for (int m : tree.released_models) store.release_slot(m);
-    tree.released_models.clear();
-    if (!updateSet.empty()) {
+    // the previous frame's batch: joined before any model slot is released or allocated -- but as late as possible: what only
+    // reads the tree (the mirror image, the cell lists) is done beside it when update() is pipelined
+    auto join_previous = [&]() {
+        finish_training();
+        ulap("updateGPs: join");
+        for (int m : tree.released_models) store.release_slot(m);
+        tree.released_models.clear();
+    };
+    if (updateSet.empty()) join_previous();
+    else {
         std::vector<int> todo(updateSet.begin(), updateSet.end());
         std::sort(todo.begin(), todo.end());
         std::vector<TrainJob> jobs;
@@ -809,9 +819,10 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
                 }
             }, 4096);
-            rc = store.upload_points(soa, (int)np, train_stream);
             ulap("updateGPs: point mirror");
         }
+        const size_t np_mirror = tree.pts.size();
+        if (!device_gather) { join_previous(); rc = store.upload_points(mirror_soa.data(), (int)np_mirror, train_stream); }
         if (rc == GPIS_OK && device_gather) {
             // K6 range part on the device: the host only names the cells (traversal order) and lists each touched cell once
             std::vector<int> cr, desc, counts, cl_of;
@@ -829,7 +840,10 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 total += capc;
             }
             counts.assign(2 * cl_of.size(), 0);
-            if (!cl_of.empty())
+            ulap("updateGPs: cell lists");
+            join_previous();
+            rc = store.upload_points(mirror_soa.data(), (int)np_mirror, train_stream);
+            if (rc == GPIS_OK && !cl_of.empty())
                 rc = store.gather_ranges(cell_lists.pts.data(), (int)cell_lists.pts.size(), cr.data(), (int)cr.size() / 2, desc.data(),
                                          (int)cl_of.size(), total, counts.data(), train_stream);
             for (size_t i = 0; i < cl_of.size() && rc == GPIS_OK; ++i) {

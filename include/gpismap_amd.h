@@ -94,11 +94,14 @@ int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 va
  * last deferred inverse pass (profiling on) */
 int   gpis3_stats(void* map, double* out, int n);
 int   gpis3_set_profile(void* map, int on);
-/* Pipelined update (opt-in: gpis3_set_pipeline(map, 1) or GPIS_PIPELINE_UPDATE=1 in the environment; the default is the
- * reference's synchronous update(), GPisMap3.cpp:218-237): gpis3_update() returns once the frame's OnGPIS training is
- * enqueued; the next update, test, statistics and the sharded exchange join it first, so results never depend on the mode --
- * only WHEN a training failure is reported does: by the call that joined.  gpis3_sync() joins explicitly and returns the
- * pending update status. */
+/* Pipelined update (the default since round 4; gpis3_set_pipeline(map, 0) or GPIS_PIPELINE_UPDATE=0 in the environment select
+ * the reference's synchronous update(), GPisMap3.cpp:218-237): gpis3_update() returns once the frame's OnGPIS training is
+ * enqueued; the next update's training, test, the getters, statistics and the sharded exchange join it first, so results never
+ * depend on the mode -- only WHEN a training failure is reported does: by the call that joined.  gpis3_sync() joins explicitly
+ * and returns the pending update status.  While it is on, the training streams are kept off GPIS_PIPELINE_RESERVE_CUS CUs
+ * (default 32, spread evenly over the XCDs) so that the next frame's ObsGP batches never wait for a factorisation workgroup.
+ * Maps that shard their training over ranks or devices run synchronously whatever the setting (every frame ends with the
+ * exchange). */
 int   gpis3_sync(void* map);
 int   gpis3_set_pipeline(void* map, int on);
 /* K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device by

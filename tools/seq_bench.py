@@ -24,6 +24,7 @@ def gpu_alone():
     frames = replay.load_bigbird(); grid = replay.demo3_grid()
     for rep in range(2):
         gm = gpismap_amd.GPisMap3(frames[0]["cam"])
+        gm.set_pipeline(False)      # per-call split as the reference's: update() includes its training
         up, te = [], []
         for i, fr in enumerate(frames):
             if i:
@@ -40,6 +41,7 @@ def main():
         return gpu_alone()
     frames = replay.load_bigbird(); grid = replay.demo3_grid()
     gm = gpismap_amd.GPisMap3(frames[0]["cam"]); om = oracle_lib.OracleMap3(frames[0]["cam"])
+    gm.set_pipeline(False)
     print("3-D (data/3D, %d frames in the fixture, %d-point demo grid): frame | points | update ms gpu/cpu | test ms gpu/cpu" % (len(frames), grid.shape[0]))
     for i, fr in enumerate(frames):
         if i:

@@ -9,10 +9,11 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 g = np.linspace(-0.9, 0.9, 28, dtype=np.float32)
 X = np.stack(np.meshgrid(0.5 * g, 0.5 * g, 1.0 + 0.2 * g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
 outs = {}
-for mode in ("default", "pipelined+eager"):
+for mode in ("synchronous", "pipelined+eager"):
     gm = gpismap_amd.GPisMap3()
-    if mode != "default":
-        gm.set_pipeline(True); gm.set_lazy_inverse(False)
+    gm.set_pipeline(mode != "synchronous")
+    if mode != "synchronous":
+        gm.set_lazy_inverse(False)
     res, t0 = [], time.perf_counter()
     for f in range(F):
         gm.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
@@ -24,5 +25,5 @@ for mode in ("default", "pipelined+eager"):
     print("%-16s %d frames %.0f ms, points %d, clusters %d, largest K of the last batch %d, pool %.1f GB" %
           (mode, F, (time.perf_counter() - t0) * 1e3, gm.num_points(), s["clusters"], s["last_train_maxK"], s["device_bytes"] / 1e9))
     outs[mode] = (gm.num_points(), res)
-a, b = outs["default"], outs["pipelined+eager"]
+a, b = outs["synchronous"], outs["pipelined+eager"]
 print("same points:", a[0] == b[0], " all test() results bit-identical:", all(np.array_equal(x, y, equal_nan=True) for x, y in zip(a[1], b[1])))

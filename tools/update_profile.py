@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Per-phase wall time of GPisMap3.update() on the synthetic 640x480 frames (host + device)."""
+"""Per-phase wall time of GPisMap3.update() on the synthetic 640x480 frames (host + device).  Synchronous update() unless
+GPIS_PIPELINE_UPDATE=1 is set (the library default is pipelined: the frame time then excludes the training it left in flight)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, gpismap_amd, replay
 gm = gpismap_amd.GPisMap3()
+gm.set_pipeline(os.environ.get("GPIS_PIPELINE_UPDATE", "0") not in ("", "0"))
 gm.set_profile(True)
 for f in range(int(sys.argv[1]) if len(sys.argv) > 1 else 4):
     d = replay.synthetic_depth(f)
