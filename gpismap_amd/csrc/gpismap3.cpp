@@ -1001,6 +1001,11 @@ static GPisMap3::Impl* make_impl(const GPisMap3Param& par, const camParam& c, co
         const int world = 1 + (int)m->peers.size();
         m->shard_rank = 0; m->shard_world = world;
         for (int r = 1; r < world; ++r) { m->peers[r - 1]->impl()->shard_rank = r; m->peers[r - 1]->impl()->shard_world = world; }
+        // several devices behind one map train synchronously (every frame ends with the model exchange): no CUs set aside
+        if (world > 1) {
+            { DeviceScope ds(m->device); m->set_pipeline(false); }
+            for (GPisMap3* q : m->peers) { DeviceScope ds(q->impl()->device); q->impl()->set_pipeline(false); }
+        }
     }
     return m;
 }
@@ -1277,6 +1282,7 @@ int gpis3_impl_set_shard(GPisMap3* g, int rank, int world) {
     GPisMap3::Impl& m = *g->impl();
     if (m.table_pending) return GPIS_ERR_STATE;
     m.shard_rank = rank; m.shard_world = world;
+    if (world > 1 && m.pipeline) { DeviceScope ds(m.device); m.set_pipeline(false); }   // sharded training is synchronous: no CUs set aside
     return GPIS_OK;
 }
 int gpis3_impl_shard_info(GPisMap3* g, int* out, int n) {
@@ -1337,14 +1343,15 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     m.finish_training();      // (the training time of the last batch is read off its events)
-    double v[24] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[26] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
                     m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK,
-                    (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs, m.stat_exchange_bytes};
-    for (int i = 0; i < n && i < 24; ++i) out[i] = v[i];
+                    (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs, m.stat_exchange_bytes,
+                    m.pipeline ? 1.0 : 0.0, (double)m.store.cu_reserve()};
+    for (int i = 0; i < n && i < 26; ++i) out[i] = v[i];
 }
 // join the training the last update() left in flight; returns the update status (0: fine)
 int gpis3_impl_sync(GPisMap3* g) {

@@ -106,3 +106,31 @@ def test_reset_and_destroy_join_the_training_in_flight():
     g2 = gpismap_amd.GPisMap3()
     g2.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
     assert g2.num_points() == n
+
+
+def test_default_mode_and_cu_reserve(monkeypatch):
+    """update() is pipelined by default and its training streams then leave CUs to the ObsGP batches of the next frame
+    (GPIS_PIPELINE_RESERVE_CUS, default 32); the synchronous mode gives the reserve back; the environment can turn the
+    default off (the unchanged mex gateway has no other switch)."""
+    monkeypatch.delenv("GPIS_PIPELINE_UPDATE", raising=False)
+    monkeypatch.delenv("GPIS_PIPELINE_RESERVE_CUS", raising=False)
+    gm = gpismap_amd.GPisMap3()
+    s = gm.stats()
+    assert s["pipelined"] == 1 and s["train_cu_reserve"] == 32
+    gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    gm.set_pipeline(False)                       # joins the training in flight, recreates the training streams unmasked
+    s = gm.stats()
+    assert s["pipelined"] == 0 and s["train_cu_reserve"] == 0
+    gm.update(replay.synthetic_depth(1), replay.IDENTITY_POSE)
+    gm.set_pipeline(True)
+    gm.update(replay.synthetic_depth(2), replay.IDENTITY_POSE)
+    ref = _run(False, frames=3)
+    assert gm.num_points() == ref[0]
+    monkeypatch.setenv("GPIS_PIPELINE_UPDATE", "0")
+    g0 = gpismap_amd.GPisMap3()
+    assert g0.stats()["pipelined"] == 0
+    monkeypatch.setenv("GPIS_PIPELINE_UPDATE", "1")
+    monkeypatch.setenv("GPIS_PIPELINE_RESERVE_CUS", "16")
+    g1 = gpismap_amd.GPisMap3()
+    s = g1.stats()
+    assert s["pipelined"] == 1 and s["train_cu_reserve"] == 16

@@ -22,18 +22,20 @@ def gpu_alone():
     """data/3D through the HIP path ALONE (no CPU oracle running its 256-thread update between the frames): VERDICT r3 asked
     whether the 12-15 ms update() outliers of the interleaved run are the oracle's doing."""
     frames = replay.load_bigbird(); grid = replay.demo3_grid()
-    for rep in range(2):
+    for rep in range(3):
         gm = gpismap_amd.GPisMap3(frames[0]["cam"])
-        gm.set_pipeline(False)      # per-call split as the reference's: update() includes its training
+        pipelined = rep == 2        # passes 1, 2: per-call split as the reference's (update() includes its training); pass 3: the default mode
+        gm.set_pipeline(pipelined)
         up, te = [], []
         for i, fr in enumerate(frames):
             if i:
                 gm.set_camera(fr["cam"])
             ug, _ = ms(gm.update, fr["depth"], fr["pose"]); tg, _ = ms(gm.test, grid)
             up.append(ug); te.append(tg)
-        print("3-D GPU alone, pass %d: update ms per frame %s" % (rep + 1, " ".join("%.1f" % v for v in up)))
+        print("3-D GPU alone, pass %d (%s): update ms per frame %s" % (rep + 1, "pipelined update, the default: test() joins the training" if pipelined else "synchronous update", " ".join("%.1f" % v for v in up)))
         print("                        test ms per frame   %s" % " ".join("%.1f" % v for v in te))
-        print("   update median of frames 2..40 %.1f ms, max %.1f ms; test median %.1f ms" % (float(np.median(up[1:])), max(up[1:]), float(np.median(te[1:]))))
+        print("   update median of frames 2..40 %.1f ms, max %.1f ms; test median %.1f ms; update + test median %.1f ms" %
+              (float(np.median(up[1:])), max(up[1:]), float(np.median(te[1:])), float(np.median(np.asarray(up[1:]) + np.asarray(te[1:])))))
 
 
 def main():
