@@ -171,7 +171,7 @@ struct GPisMap3::Impl {
              (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
              (hipStreamCreateWithPriority(&train_stream, hipStreamNonBlocking, pr_least) == hipSuccess) &&
              (hipStreamCreateWithFlags(&batch_stream, hipStreamNonBlocking) == hipSuccess);
-        if (const char* e = getenv("GPIS_PIPELINE_RESERVE_CUS")) pipeline_reserve = std::max(0, atoi(e));
+        if (const char* e = getenv("GPIS_PIPELINE_RESERVE_CUS")) { pipeline_reserve = std::max(0, atoi(e)); pipeline_reserve_set = true; }
         // update() is pipelined by default: it returns once the frame's training is enqueued; whatever needs the models (the
         // next training, test(), the getters, gpis3_sync) joins it.  GPIS_PIPELINE_UPDATE=0 / gpis3_set_pipeline(map, 0): every
         // update() joins its own training before it returns, like the reference's.
@@ -201,9 +201,15 @@ struct GPisMap3::Impl {
     // `pipeline_reserve` CUs (spread evenly over the XCDs): the ObsGP kernels -- highest priority, unmasked -- start at once
     // there (measured, tools/ubench/cumask_probe.hip: 6 us instead of 2 ms beside a busy unmasked stream).
     int pipeline_reserve = 32;
+    bool pipeline_reserve_set = false;
     void set_pipeline(bool on) {
         (void)store.train_finish();
-        const int want = on ? pipeline_reserve : 0;
+        int want = 0;
+        if (on) {
+            int ncu = 0;
+            (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
+            want = pipeline_reserve_set ? pipeline_reserve : std::min(pipeline_reserve, ncu / 8);    // default: an eighth of the device, at most 32 CUs
+        }
         if (want != store.cu_reserve()) {
             (void)store.set_cu_reserve(want);
             hipStream_t ns = nullptr;
