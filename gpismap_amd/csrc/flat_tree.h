@@ -237,10 +237,12 @@ public:
         const int c = walk_start(p);
         if (c == root || c < 0) return remove(root, p, set);
         if (!remove(c, p, set)) return false;
-        for (int a = nodes[c].par; a >= 0; a = nodes[a].par) {
+        // (an ancestor can only collapse when its child on the path has just become an empty leaf: the walk stops at the first
+        // one that has not -- every ancestor above it keeps an inner node among its children)
+        for (int below = c, a = nodes[c].par; a >= 0 && empty_leaf(below); below = a, a = nodes[a].par) {
             bool all = true;
             for (int i = 0; i < NC && all; ++i) all = empty_leaf(nodes[a].ch[i]);
-            if (!all) continue;
+            if (!all) break;
             for (int i = 0; i < NC; ++i) {
                 if (set) set->erase(nodes[a].ch[i]);
                 free_subtree(nodes[a].ch[i]);
