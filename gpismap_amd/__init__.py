@@ -63,6 +63,8 @@ def lib():
     L.gpis3_test.argtypes = [vp, fp, C.c_int, C.c_int, fp]
     L.gpis3_test_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.gpis3_num_points.argtypes = [vp]
+    L.gpis3_save.argtypes = [vp, C.c_char_p]
+    L.gpis3_load.argtypes = [vp, C.c_char_p]
     L.gpis3_get_points.argtypes = [vp, fp, C.c_int]
     L.gpis3_get_nodes.argtypes = [vp, fp, C.c_int]
     L.gpis3_stats.argtypes = [vp, dp, C.c_int]
@@ -246,6 +248,14 @@ class GPisMap3:
         a = (C.c_double * 26)()
         _check(self.L.gpis3_stats(self.h, a, 26), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
+
+    def save(self, path):
+        """Map checkpoint: spatial index + surface points (gpis3_save)."""
+        _check(self.L.gpis3_save(self.h, os.fsencode(path)), "gpis3_save")
+
+    def load(self, path):
+        """Replace the map's state with a checkpoint's and retrain its clusters (gpis3_load)."""
+        _check(self.L.gpis3_load(self.h, os.fsencode(path)), "gpis3_load")
 
     def set_profile(self, on=True):
         _check(self.L.gpis3_set_profile(self.h, int(on)), "gpis3_set_profile")

@@ -135,6 +135,13 @@ int gpis3_get_nodes(void* m, float* out, int cap) {
     if (out && n <= cap && n > 0) std::memcpy(out, p.data(), p.size() * sizeof(float));
     return n;
 }
+int gpis3_save(void* m, const char* path) { if (!m || !path) return GPIS_ERR_ARG; return ((GPisMap3*)m)->saveMap(path) ? GPIS_OK : GPIS_ERR_ARG; }
+int gpis3_load(void* m, const char* path) {
+    if (!m || !path) return GPIS_ERR_ARG;
+    if (((GPisMap3*)m)->loadMap(path)) return GPIS_OK;
+    const int rc = gpis3_impl_update_fail((GPisMap3*)m);
+    return rc ? rc : GPIS_ERR_ARG;
+}
 int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_ARG; gpis3_impl_stats((GPisMap3*)m, out, n); return GPIS_OK; }
 int gpis3_sync(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_sync((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_pipeline(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis3_impl_set_pipeline((GPisMap3*)m, on); return GPIS_OK; } catch (...) { return GPIS_ERR_STATE; } }

@@ -1280,6 +1280,133 @@ void GPisMap3::getAllNodes(std::vector<float>& out) try {
     }
 } catch (const std::exception& e) { nothrow_report("GPisMap3::getAllNodes", e.what()); } catch (...) { nothrow_report("GPisMap3::getAllNodes", "unknown exception"); }
 
+// ------------------------------------------------------------------ checkpoint ----
+// File: header, tree parameters, the flat tree's vectors as they are (nodes, points, free lists), the cluster cells that carry a
+// trained model with the byte offsets of their records, then the packed records themselves (model_pack.hip: what prediction
+// reads -- row table, points, X = L^-1 with alpha).  The models travel as they are, not as something to retrain: the
+// reference's update leaves a model stale when a point is removed without its cell being re-activated, and a reloaded map
+// must answer exactly as the saved one did.
+namespace {
+struct CkptHeader {
+    char magic[8];
+    unsigned version, dim, sz_node, sz_point, sz_param;
+    int root, has_tree;
+    unsigned long long n_nodes, n_pts, n_free_nodes, n_free_pts, n_pending, n_models, model_bytes;
+};
+const char kCkptMagic[8] = {'G', 'P', 'I', 'S', '3', 'C', 'K', '1'};
+template <class T> bool wr_vec(FILE* f, const std::vector<T>& v) { return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
+template <class T> bool rd_vec(FILE* f, std::vector<T>& v, size_t n) { v.resize(n); return n == 0 || fread(v.data(), sizeof(T), n, f) == n; }
+}  // namespace
+
+bool GPisMap3::saveMap(const char* path) try {
+    Impl& m = *p_;
+    if (!path || !m.ok) return false;
+    DeviceScope ds(m.device);
+    if (m.finish_training() != GPIS_OK || m.table_pending) return false;
+    std::vector<int> cl, cells;
+    std::vector<int> slots;
+    std::vector<unsigned long long> offs(1, 0);
+    if (m.has_tree) m.tree.all_clusters(cl);
+    for (int c : cl) {
+        const int slot = m.tree.nodes[c].model;
+        const ClusterModel* md = slot >= 0 ? m.store.model(slot) : nullptr;
+        if (!md || md->N <= 0 || md->K <= 0) continue;        // (a cell whose training failed has a slot without a model: no GP there, saved as none)
+        cells.push_back(c); slots.push_back(slot);
+        offs.push_back(offs.back() + packed_model_bytes(md->ld, md->N));
+    }
+    const size_t total = (size_t)offs.back();
+    std::vector<char> bytes(total);
+    if (total) {
+        void* d_buf = nullptr;
+        if (hipMalloc(&d_buf, total) != hipSuccess) return false;
+        std::vector<size_t> o(offs.begin(), offs.end());
+        int rc = m.store.pack_models(slots.data(), (int)slots.size(), d_buf, 0, m.stream, o.data());
+        if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
+        if (rc == GPIS_OK && hipMemcpy(bytes.data(), d_buf, total, hipMemcpyDeviceToHost) != hipSuccess) rc = GPIS_ERR_HIP;
+        (void)hipFree(d_buf);
+        if (rc != GPIS_OK) return false;
+    }
+    FILE* f = fopen(path, "wb");
+    if (!f) return false;
+    CkptHeader h;
+    std::memset(&h, 0, sizeof(h));
+    std::memcpy(h.magic, kCkptMagic, 8);
+    h.version = 1; h.dim = 3; h.sz_node = (unsigned)sizeof(FlatTree<3>::TNode); h.sz_point = (unsigned)sizeof(FlatPoint<3>); h.sz_param = (unsigned)sizeof(FlatTreeParam);
+    h.root = m.tree.root; h.has_tree = m.has_tree ? 1 : 0;
+    h.n_nodes = m.tree.nodes.size(); h.n_pts = m.tree.pts.size(); h.n_free_nodes = m.tree.free_nodes.size();
+    h.n_free_pts = m.tree.free_pts.size(); h.n_pending = m.tree.pending_free_pts.size();
+    h.n_models = cells.size(); h.model_bytes = total;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&m.tree.prm, sizeof(FlatTreeParam), 1, f) == 1 &&
+              wr_vec(f, m.tree.nodes) && wr_vec(f, m.tree.pts) && wr_vec(f, m.tree.free_nodes) && wr_vec(f, m.tree.free_pts) &&
+              wr_vec(f, m.tree.pending_free_pts) && wr_vec(f, cells) && wr_vec(f, offs) && wr_vec(f, bytes);
+    ok = (fclose(f) == 0) && ok;
+    return ok;
+} catch (const std::exception& e) { nothrow_report("GPisMap3::saveMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::saveMap", "unknown exception"); return false; }
+
+bool GPisMap3::loadMap(const char* path) try {
+    if (p_->peers.empty() || p_->shard_rank != 0) return loadMap_one(path);
+    // several devices behind one map: every device keeps a full copy of the models -- each rank loads the file
+    std::vector<int> okv(1 + p_->peers.size(), 0);
+    for_each_rank(*p_, [&](int r, GPisMap3* q) { okv[r] = (r == 0 ? loadMap_one(path) : q->loadMap_one(path)) ? 1 : 0; });
+    for (int v : okv) if (!v) return false;
+    return true;
+} catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
+
+bool GPisMap3::loadMap_one(const char* path) try {
+    Impl& m = *p_;
+    if (!path || !m.ok) return false;
+    DeviceScope ds(m.device);
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+    CkptHeader h;
+    FlatTreeParam prm;
+    if (fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != 1 || h.dim != 3 ||
+        h.sz_node != sizeof(FlatTree<3>::TNode) || h.sz_point != sizeof(FlatPoint<3>) || h.sz_param != sizeof(FlatTreeParam)) return false;
+    {   // another tree geometry (field by field: the struct has padding)
+        const FlatTreeParam& q = m.tree.prm;
+        if (fread(&prm, sizeof(prm), 1, f) != 1 || prm.init_half != q.init_half || prm.min_half != q.min_half || prm.min_half_sq != q.min_half_sq ||
+            prm.max_half != q.max_half || prm.cluster_half != q.cluster_half || prm.cluster_eps != q.cluster_eps ||
+            prm.qleaf_eps_plain != q.qleaf_eps_plain || prm.qleaf_eps_dist != q.qleaf_eps_dist || prm.qdesc_eps != q.qdesc_eps) return false;
+    }
+    const unsigned long long lim = 1ull << 31;
+    if (h.n_nodes >= lim || h.n_pts >= lim || h.n_free_nodes > h.n_nodes || h.n_free_pts > h.n_pts || h.n_pending > h.n_pts || h.n_models > h.n_nodes) return false;
+    std::vector<FlatTree<3>::TNode> nodes; std::vector<FlatPoint<3>> pts;
+    std::vector<int> free_nodes, free_pts, pending, cells;
+    std::vector<unsigned long long> offs;
+    std::vector<char> bytes;
+    if (!rd_vec(f, nodes, (size_t)h.n_nodes) || !rd_vec(f, pts, (size_t)h.n_pts) || !rd_vec(f, free_nodes, (size_t)h.n_free_nodes) ||
+        !rd_vec(f, free_pts, (size_t)h.n_free_pts) || !rd_vec(f, pending, (size_t)h.n_pending) || !rd_vec(f, cells, (size_t)h.n_models) ||
+        !rd_vec(f, offs, (size_t)h.n_models + 1) || offs.back() != h.model_bytes || !rd_vec(f, bytes, (size_t)h.model_bytes)) return false;
+    if (h.has_tree && (h.root < 0 || (unsigned long long)h.root >= h.n_nodes)) return false;
+    for (int c : cells) if (c < 0 || (unsigned long long)c >= h.n_nodes) return false;
+    // the file is consistent: replace the map
+    (void)m.finish_training();
+    m.upd_rc = 0;
+    m.reset();
+    m.shard_jobs.clear(); m.table_pending = false;
+    for (FlatTree<3>::TNode& t : nodes) t.model = -1;
+    m.tree.nodes.swap(nodes); m.tree.pts.swap(pts); m.tree.free_nodes.swap(free_nodes); m.tree.free_pts.swap(free_pts);
+    m.tree.pending_free_pts.swap(pending); m.tree.released_models.clear();
+    m.tree.root = h.has_tree ? h.root : -1; m.tree.last_cell = -1;
+    m.has_tree = h.has_tree != 0;
+    int rc = GPIS_OK;
+    if (!cells.empty()) {
+        void* d_buf = nullptr;
+        if (hipMalloc(&d_buf, bytes.size()) != hipSuccess) rc = GPIS_ERR_HIP;
+        if (rc == GPIS_OK && hipMemcpy(d_buf, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) rc = GPIS_ERR_HIP;
+        std::vector<int> slots(cells.size(), -1);
+        std::vector<size_t> o(offs.begin(), offs.end());
+        if (rc == GPIS_OK) rc = m.store.unpack_models(d_buf, (int)cells.size(), 0, slots.data(), m.stream, o.data());
+        if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
+        if (d_buf) (void)hipFree(d_buf);
+        if (rc == GPIS_OK) for (size_t i = 0; i < cells.size(); ++i) m.tree.nodes[cells[i]].model = slots[i];
+    }
+    if (rc != GPIS_OK) { m.upd_rc = rc; m.reset(); return false; }
+    m.build_cluster_table();
+    return m.upd_rc == 0;
+} catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
+
 // accessors used by the C-ABI (capi.cpp)
 int gpis3_impl_fail(GPisMap3* g) { return g->impl()->fail_rc; }
 int gpis3_impl_device(GPisMap3* g) { return g->impl()->device; }

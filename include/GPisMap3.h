@@ -87,6 +87,12 @@ public:
     bool test_one(float* x, int dim, int leng, float* res);
     bool testDevice(const float* d_x, int leng, float* d_res, void* hip_stream);
     void getAllNodes(std::vector<float>& out9);  /* pos3 grad3 val sigx sigg, tree order */
+    /* Map checkpoint (optional; the reference has none): the spatial index and the surface points with their
+     * data as one binary file.  loadMap() replaces the map (the camera stays) and retrains every cluster that holds points --
+     * the models are a function of the points, so test() answers with the same bits as before the save. */
+    bool saveMap(const char* path);
+    bool loadMap(const char* path);
+    bool loadMap_one(const char* path);   /* this object's own device only */
     struct Impl;
     Impl* impl() { return p_; }
 

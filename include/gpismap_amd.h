@@ -94,6 +94,12 @@ int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 va
  * last deferred inverse pass (profiling on), bytes received in the last in-library model exchange, pipelined update on (0/1),
  * CUs the training streams leave free */
 int   gpis3_stats(void* map, double* out, int n);
+/* Map checkpoint (optional; the reference keeps its map only in the mex singleton): gpis3_save writes the spatial
+ * index and the surface points with their data (GPisMap3::saveMap); gpis3_load replaces the map's state with a file's and
+ * retrains every cluster that holds points -- same test() bits as before the save, and the next update continues from it.
+ * The file is a raw image of this build's structures (refused by another build: GPIS_ERR_ARG); the camera is not part of it. */
+int   gpis3_save(void* map, const char* path);
+int   gpis3_load(void* map, const char* path);
 int   gpis3_set_profile(void* map, int on);
 /* Pipelined update (the default since round 4; gpis3_set_pipeline(map, 0) or GPIS_PIPELINE_UPDATE=0 in the environment select
  * the reference's synchronous update(), GPisMap3.cpp:218-237): gpis3_update() returns once the frame's OnGPIS training is
