@@ -105,7 +105,13 @@ struct GPisMap::Impl {
     bool query(std::vector<float>& q, std::vector<float>& val, std::vector<float>& var) {
         val.assign(q.size(), 0.f); var.assign(q.size(), 1e6f);
         if (q.empty()) return true;
-        int rc = gpo.query(q.data(), (int)q.size(), val.data(), var.data(), stream);
+        // through the ObsGP object's page-locked staging (a re-evaluation is up to a dozen dependent round trips: copies out of
+        // pageable vectors are staged by the runtime, 20-40 us each)
+        const int nq = (int)q.size();
+        float* hq = gpo.stage_q(nq);
+        int rc = hq ? GPIS_OK : GPIS_ERR_HIP;
+        if (rc == GPIS_OK) { std::memcpy(hq, q.data(), sizeof(float) * (size_t)nq); rc = gpo.query_staged(nq, stream); }
+        if (rc == GPIS_OK) { val.assign(gpo.staged_val(), gpo.staged_val() + nq); var.assign(gpo.staged_var(), gpo.staged_var() + nq); }
         if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] ObsGP query failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; return false; }
         stat_obs_queries += (long)q.size();
         return true;
