@@ -307,6 +307,22 @@ int ObsGPDevice::query_staged(int nq, hipStream_t s) {
     if (!trained_) return GPIS_ERR_STATE;
     if (nq <= 0) return GPIS_OK;
     if (nq > cap_hq_ || !h_q_ || !h_val_ || !h_var_) return GPIS_ERR_STATE;
+    // Small batches (the line-search rounds of the 2-D re-evaluation, late re-evaluations in 3-D: dependent round trips of a
+    // few hundred queries): the kernel reads the queries from and writes the answers into the page-locked staging itself --
+    // one launch and one synchronisation instead of a copy in, a memset, the launch and two copies out.
+    constexpr int kZeroCopyMax = 4096;      // (below the binned path's threshold; a lane reads 4-8 bytes and writes 8 over the host link)
+    if (nq < kZeroCopyMax) {
+        float *zq = nullptr, *zval = nullptr, *zvar = nullptr;
+        if (hipHostGetDevicePointer((void**)&zq, h_q_, 0) == hipSuccess && hipHostGetDevicePointer((void**)&zval, h_val_, 0) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&zvar, h_var_, 0) == hipSuccess) {
+            std::memset(h_val_, 0, sizeof(float) * (size_t)nq);
+            obsgp_launch_query(view_, zq, nq, zval, zvar, s);
+            GPIS_HIP(hipGetLastError());
+            GPIS_HIP(hipStreamSynchronize(s));
+            return GPIS_OK;
+        }
+        (void)hipGetLastError();
+    }
     int rc = ensure_q(nq);
     if (rc) return rc;
     const int per = (view_.mode == 2) ? 2 : 1;
