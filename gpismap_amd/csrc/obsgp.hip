@@ -141,49 +141,14 @@ __device__ __forceinline__ int obsgp_lookup1(const ObsGPView& v, float q0) {
     return -1;
 }
 
-// K2, lanes = queries.  A wavefront takes 64 consecutive queries, looks their groups up (lane = query) and then serves
-// one DISTINCT group at a time: the group's factor (n columns, <= 16 KB), inputs and alpha are staged in LDS once, and every
-// lane whose query belongs to the group runs the whole prediction for its own query with the k* vector in registers --
-//   k_i = OU(x_i, q),  mean = tree sum of k_i alpha_i,  forward substitution  v_j = k_j / L_jj ; k_i -= L_ij v_j (i > j),
-//   var = (1 + noise) - sum v_j^2
-// The operations per query are exactly the ones of the one-wavefront-per-query formulation (chains (O1), (O5), the 64-slot
-// butterfly (O4) written out as the same pairwise tree), so the results are bit-identical to it; but the factor is read
-// once per (wavefront, group) instead of once per query, and the substitution costs ~45 instructions per query instead of
-// ~1200.  update()'s batches are coherent (the 7 queries of a pixel and its neighbours share a group), so a wavefront
-// usually sees one to three groups.  Worst case (64 different groups) it degenerates to one group per pass.
-// PERM: the wave takes the queries perm[64 b .. 64 b + 63] (queries sorted by group on the device: obsgp_bin_* below), so that a
-// wave meets one or two groups instead of every group its 64 consecutive queries happen to fall into; lanes are independent,
-// so the order does not touch any result.  ngq = number of queries that have a group (the sorted list's length).
-template <bool PERM>
-__global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
-                                                         float* __restrict__ val, float* __restrict__ var,
-                                                         const int* __restrict__ perm, const int* __restrict__ gq, const int* __restrict__ ngq) {
-    // one 16 KB buffer, used twice per group: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those
-    // are in registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j))
-    __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
-    __shared__ __attribute__((aligned(16))) float sx[128];
-    __shared__ __attribute__((aligned(16))) float sa[64];
-    const int lane = threadIdx.x;
-    const int slot = blockIdx.x * 64 + lane;
-    const bool have = PERM ? (slot < *ngq) : (slot < nq);
-    const int qi = PERM ? (have ? perm[slot] : 0) : slot;
-    float q0 = 0.f, q1 = 0.f;
-    if (have) {
-        if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
-        else q0 = q[qi];
-    }
-    int g = -1;
-    if (have) g = PERM ? gq[qi] : ((v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0));
-    if (!PERM && have && g < 0) var[qi] = 1e6f;
-    bool pending = have && g >= 0;
+// One group's share of a wavefront's queries: the lanes with `mine` hold a query (q0, q1) of group gt; its mean and variance
+// go to val[qi] / var[qi].  sbuf is used twice: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those are in
+// registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j)).  All 64 lanes call it (barriers inside).
+__device__ __forceinline__ void obsgp_query_group(const ObsGPView& v, int gt, bool mine, float q0, float q1, int qi, int lane,
+                                                  float* __restrict__ val, float* __restrict__ var, float* sbuf, float* sx, float* sa) {
     const float a = 1 / OU_SCALE;
-    for (;;) {
-        const unsigned long long todo = __ballot(pending);
-        if (todo == 0ull) break;
-        const int leader = __ffsll((long long)todo) - 1;
-        const int gt = __builtin_amdgcn_readlane(g, leader);
+    {
         const int n = v.tn[gt];
-        const bool mine = pending && g == gt;
         sx[lane] = v.tx[(size_t)gt * 128 + lane];
         sx[64 + lane] = v.tx[(size_t)gt * 128 + 64 + lane];
         sa[lane] = v.talpha[(size_t)gt * 64 + lane];
@@ -230,7 +195,80 @@ __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const floa
             val[qi] = s[0];
             var[qi] = (1 + OU_NOISE) - acc;  // ObsGP.cpp:61
         }
+    }
+}
+
+// K2, lanes = queries.  A wavefront takes 64 consecutive queries, looks their groups up (lane = query) and then serves
+// one DISTINCT group at a time: the group's factor (n columns, <= 16 KB), inputs and alpha are staged in LDS once, and every
+// lane whose query belongs to the group runs the whole prediction for its own query with the k* vector in registers --
+//   k_i = OU(x_i, q),  mean = tree sum of k_i alpha_i,  forward substitution  v_j = k_j / L_jj ; k_i -= L_ij v_j (i > j),
+//   var = (1 + noise) - sum v_j^2
+// The operations per query are exactly the ones of the one-wavefront-per-query formulation (chains (O1), (O5), the 64-slot
+// butterfly (O4) written out as the same pairwise tree), so the results are bit-identical to it; but the factor is read
+// once per (wavefront, group) instead of once per query, and the substitution costs ~45 instructions per query instead of
+// ~1200.  update()'s batches are coherent (the 7 queries of a pixel and its neighbours share a group), so a wavefront
+// usually sees one to three groups.  Worst case (64 different groups) it degenerates to one group per pass.
+// PERM: the wave takes the queries perm[64 b .. 64 b + 63] (queries sorted by group on the device: obsgp_bin_* below), so that a
+// wave meets one or two groups instead of every group its 64 consecutive queries happen to fall into; lanes are independent,
+// so the order does not touch any result.  ngq = number of queries that have a group (the sorted list's length).
+template <bool PERM>
+__global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const float* __restrict__ q, int nq,
+                                                         float* __restrict__ val, float* __restrict__ var,
+                                                         const int* __restrict__ perm, const int* __restrict__ gq, const int* __restrict__ ngq) {
+    // one 16 KB buffer, used twice per group: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those
+    // are in registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j))
+    __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sx[128];
+    __shared__ __attribute__((aligned(16))) float sa[64];
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x * 64 + lane;
+    const bool have = PERM ? (slot < *ngq) : (slot < nq);
+    const int qi = PERM ? (have ? perm[slot] : 0) : slot;
+    float q0 = 0.f, q1 = 0.f;
+    if (have) {
+        if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
+        else q0 = q[qi];
+    }
+    int g = -1;
+    if (have) g = PERM ? gq[qi] : ((v.mode == 2) ? obsgp_lookup2(v, q0, q1) : obsgp_lookup1(v, q0));
+    if (!PERM && have && g < 0) var[qi] = 1e6f;
+    bool pending = have && g >= 0;
+    for (;;) {
+        const unsigned long long todo = __ballot(pending);
+        if (todo == 0ull) break;
+        const int leader = __ffsll((long long)todo) - 1;
+        const int gt = __builtin_amdgcn_readlane(g, leader);
+        const bool mine = pending && g == gt;
+        obsgp_query_group(v, gt, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa);
         pending = pending && !mine;
+        __syncthreads();
+    }
+}
+
+// The same for a batch that was sorted by group: workgroup (g, c) of kQueryChunks per group takes the chunks c, c + kQueryChunks,
+// ... of 64 queries of group g (base / count: the counting sort's prefix and fill arrays).  A wavefront meets exactly ONE group
+// per chunk; with 64 consecutive entries of the sorted list per wavefront (the first binned version) a batch with ten queries per
+// group -- the centre queries of a re-evaluation -- made every wavefront walk through six or seven groups one after the other
+// (0.42 ms for 30 000 queries; the 537 000 pixel queries took 0.28).
+constexpr int kQueryChunks = 4;
+__global__ __launch_bounds__(64) void obsgp_query_grouped_kernel(ObsGPView v, const float* __restrict__ q, float* __restrict__ val, float* __restrict__ var,
+                                                                 const int* __restrict__ perm, const int* __restrict__ base, const int* __restrict__ count) {
+    __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
+    __shared__ __attribute__((aligned(16))) float sx[128];
+    __shared__ __attribute__((aligned(16))) float sa[64];
+    const int lane = threadIdx.x;
+    const int g = blockIdx.x / kQueryChunks, c0 = blockIdx.x % kQueryChunks;
+    const int b = base[g], cnt = count[g];
+    for (int chunk = c0; chunk * 64 < cnt; chunk += kQueryChunks) {
+        const int idx = chunk * 64 + lane;
+        const bool mine = idx < cnt;
+        const int qi = mine ? perm[b + idx] : 0;
+        float q0 = 0.f, q1 = 0.f;
+        if (mine) {
+            if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
+            else q0 = q[qi];
+        }
+        obsgp_query_group(v, g, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa);
         __syncthreads();
     }
 }
@@ -283,8 +321,8 @@ void obsgp_launch_query_binned(const ObsGPView& v, const float* d_q, int nq, flo
     hipLaunchKernelGGL(obsgp_bin_count_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, v, d_q, nq, gq, cnt, d_var);
     hipLaunchKernelGGL(obsgp_bin_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, v.ngroups);
     hipLaunchKernelGGL(obsgp_bin_scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, gq, nq, cnt, fill, perm);
-    // (the sorted list holds at most nq queries; waves beyond its length find nothing to do)
-    hipLaunchKernelGGL(obsgp_query_kernel<true>, dim3((nq + 63) / 64), dim3(64), 0, s, v, d_q, nq, d_val, d_var, perm, gq, cnt + v.ngroups);
+    // (cnt: start of every group in the sorted list, fill: its length)
+    hipLaunchKernelGGL(obsgp_query_grouped_kernel, dim3(v.ngroups * kQueryChunks), dim3(64), 0, s, v, d_q, d_val, d_var, perm, cnt, fill);
 }
 
 }  // namespace gpis
