@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=5, help="synthetic depth frames fused before testing (SURVEY 8d: F = 5)")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
-    ap.add_argument("--update-repeats", type=int, default=3, help="fuse the frame sequence this many times (fresh maps); headline = median of frames 2..F of the MEDIAN repeat (the minimum over the repeats is a side field)")
+    ap.add_argument("--update-repeats", type=int, default=5, help="fuse the frame sequence this many times (fresh maps); headline = median of frames 2..F of the MEDIAN repeat (the minimum over the repeats is a side field)")
     ap.add_argument("--train", default="replicated", choices=["replicated", "sharded"], help="multi-rank update(): every rank trains everything, or its K^3-balanced share + all-gather of the models")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: transfers staged through host memory)")
     ap.add_argument("--block", type=int, default=65536, help="queries per block of the block-cyclic cut")
