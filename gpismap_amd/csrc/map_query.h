@@ -86,6 +86,12 @@ private:
     int* d_tie_ = nullptr;      // [1] queries with an exact distance tie among their nearest candidates (list: d_jq_, free at that time)
     std::vector<int> h_maxN_, h_maxLd_;   // per class: largest N and ld (LDS sizing of K4)
     hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+    // K4 launches of one pass (one per size class, disjoint tiles and outputs) run beside each other: the first on the caller's
+    // stream, the rest on side streams forked from and joined to it
+    static constexpr int kSide = 3;
+    hipStream_t side_[kSide] = {nullptr, nullptr, nullptr};
+    hipEvent_t evfork_ = nullptr, evjoin_[kSide] = {nullptr, nullptr, nullptr};
+    bool side_off_ = false;
 };
 
 }  // namespace gpis
