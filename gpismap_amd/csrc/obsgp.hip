@@ -245,14 +245,16 @@ __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const floa
     }
 }
 
-// The same for a batch that was sorted by group: workgroup (g, c) of kQueryChunks per group takes the chunks c, c + kQueryChunks,
+// The same for a batch that was sorted by group: workgroup (g, c) of kQueryChunks per group (1 ... 4 by the batch's mean
+// queries per group: empty workgroups cost dispatch time, most of all while the training of the previous frame holds the CUs)
+// takes the chunks c, c + kQueryChunks,
 // ... of 64 queries of group g (base / count: the counting sort's prefix and fill arrays).  A wavefront meets exactly ONE group
 // per chunk; with 64 consecutive entries of the sorted list per wavefront (the first binned version) a batch with ten queries per
 // group -- the centre queries of a re-evaluation -- made every wavefront walk through six or seven groups one after the other
 // (0.42 ms for 30 000 queries; the 537 000 pixel queries took 0.28).
-constexpr int kQueryChunks = 4;
 __global__ __launch_bounds__(64) void obsgp_query_grouped_kernel(ObsGPView v, const float* __restrict__ q, float* __restrict__ val, float* __restrict__ var,
-                                                                 const int* __restrict__ perm, const int* __restrict__ base, const int* __restrict__ count) {
+                                                                 const int* __restrict__ perm, const int* __restrict__ base, const int* __restrict__ count,
+                                                                 int kQueryChunks) {
     __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
     __shared__ __attribute__((aligned(16))) float sx[128];
     __shared__ __attribute__((aligned(16))) float sa[64];
@@ -322,7 +324,8 @@ void obsgp_launch_query_binned(const ObsGPView& v, const float* d_q, int nq, flo
     hipLaunchKernelGGL(obsgp_bin_scan_kernel, dim3(1), dim3(1024), 0, s, cnt, v.ngroups);
     hipLaunchKernelGGL(obsgp_bin_scatter_kernel, dim3((nq + 255) / 256), dim3(256), 0, s, gq, nq, cnt, fill, perm);
     // (cnt: start of every group in the sorted list, fill: its length)
-    hipLaunchKernelGGL(obsgp_query_grouped_kernel, dim3(v.ngroups * kQueryChunks), dim3(64), 0, s, v, d_q, d_val, d_var, perm, cnt, fill);
+    const int chunks = std::max(1, std::min(4, (int)((3 * (long long)nq / std::max(1, v.ngroups) + 127) / 128)));   // ~1.5 x the mean chunks per group
+    hipLaunchKernelGGL(obsgp_query_grouped_kernel, dim3(v.ngroups * chunks), dim3(64), 0, s, v, d_q, d_val, d_var, perm, cnt, fill, chunks);
 }
 
 }  // namespace gpis
