@@ -237,7 +237,7 @@ struct GPisMap3::Impl {
     void updateMapPoints();
     void evalPoints();
     void updateGPs();
-    int try_insert(int pid, T3::InsSet& ins);
+    int try_insert(int pid, T3::InsSet& ins, bool known_new = false);
 
     struct Stage2 {   // per point, after the centre query
         bool go = false;        // survives the var / occupancy gates
@@ -353,9 +353,11 @@ bool GPisMap3::Impl::regressObs() {  // :239-256 -> K1
 // reported (the caller then fills in its data), 1 when it was stored through the set-less
 // root-growth path (octree.cpp:151-212: it stays in the tree with default data, as in the
 // reference), 0 when it was not stored (the point object is released).
-int GPisMap3::Impl::try_insert(int pid, T3::InsSet& ins) {
+int GPisMap3::Impl::try_insert(int pid, T3::InsSet& ins, bool known_new) {
     bool ok_ = false;
-    if (!tree.is_not_new_cached(tree.pts[pid].pos)) {
+    // (known_new: the caller has just asked is_not_new() for this position and nothing touched the tree since -- the
+    // reference's second IsNotNew inside its insert helper would give the same answer)
+    if (known_new || !tree.is_not_new_cached(tree.pts[pid].pos)) {
         ok_ = tree.insert_cached(pid, &ins);
         if (ok_ && !tree.is_root(tree.root)) tree.root = tree.get_root(tree.root);
     }
@@ -761,7 +763,7 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
         if (tree.is_not_new_cached(&obs_valid_xyzglobal[3 * (size_t)k])) continue;
         int pid = tree.new_point(&obs_valid_xyzglobal[3 * (size_t)k]);
         T3::InsSet ins;
-        if (try_insert(pid, ins) != 2) continue;
+        if (try_insert(pid, ins, true) != 2) continue;
 #ifdef GPIS_INSTRUMENT
         ++dbg_ins;
 #endif
