@@ -142,3 +142,25 @@ def test_obsgp1d_query_kernel_matches_oracle():
     print("1-D queries %d answered %d bit-identical %.6f" % (q.shape[0], int(hit.sum()), same))
     assert same >= 0.9995
     assert np.abs(val[hit] - oval[hit]).max() < 1e-5 and np.abs(var[hit] - ovar[hit]).max() < 1e-5
+
+
+def test_query_batches_of_every_size_give_the_same_bits():
+    """K2 has three launch shapes: unsorted (below 4096 queries), and sorted by group with one to four workgroups per group
+    (by the batch's mean queries per group).  A query's answer must not depend on the batch it travels in."""
+    import gpismap_amd
+    g = gpismap_amd.ObsGP()
+    om = _oracle_after(1, g)
+    vu, zinv, ni, nj = om.obs()
+    rng = np.random.default_rng(11)
+    valid = np.nonzero(zinv > 0)[0]
+    c = np.stack([vu[2 * valid], vu[2 * valid + 1]], axis=1)
+    big = np.concatenate([c + rng.normal(0, 1e-3, c.shape).astype(np.float32) for _ in range(3)]).astype(np.float32)   # ~150 queries per group: 4 workgroups per group
+    vb, rb = g.query(big)
+    assert (rb < 1e5).sum() > 100000
+    # the same queries in slices of 3000 (unsorted kernel), 5000 (sorted, one workgroup per group) and 60 000 (two)
+    for step in (3000, 5000, 60000):
+        idx = rng.permutation(big.shape[0])[: 4 * step]
+        for k in range(0, idx.size, step):
+            sel = idx[k:k + step]
+            v, r = g.query(np.ascontiguousarray(big[sel]))
+            assert np.array_equal(v, vb[sel]) and np.array_equal(r, rb[sel]), step
