@@ -154,12 +154,14 @@ def test_query_batches_of_every_size_give_the_same_bits():
     rng = np.random.default_rng(11)
     valid = np.nonzero(zinv > 0)[0]
     c = np.stack([vu[2 * valid], vu[2 * valid + 1]], axis=1)
-    big = np.concatenate([c + rng.normal(0, 1e-3, c.shape).astype(np.float32) for _ in range(3)]).astype(np.float32)   # ~150 queries per group: 4 workgroups per group
+    reps = 420000 // c.shape[0] + 1
+    big = np.concatenate([c + rng.normal(0, 1e-3, c.shape).astype(np.float32) for _ in range(reps)]).astype(np.float32)   # > 128 queries per group on average: 4 workgroups per group
+    assert big.shape[0] > 128 * g.num_groups()
     vb, rb = g.query(big)
     assert (rb < 1e5).sum() > 100000
-    # the same queries in slices of 3000 (unsorted kernel), 5000 (sorted, one workgroup per group) and 60 000 (two)
-    for step in (3000, 5000, 60000):
-        idx = rng.permutation(big.shape[0])[: 4 * step]
+    # the same queries in slices of 3000 (unsorted kernel), 5000 (sorted, one workgroup per group) and 150 000 (two)
+    for step in (3000, 5000, 150000):
+        idx = rng.permutation(big.shape[0])[: 2 * step]
         for k in range(0, idx.size, step):
             sel = idx[k:k + step]
             v, r = g.query(np.ascontiguousarray(big[sel]))
