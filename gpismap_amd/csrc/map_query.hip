@@ -531,18 +531,20 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     // stream, the others on side streams forked from it and joined back -- a demo-sized grid spends its time in the critical
     // path of each launch (one tile of the largest clusters: 0.3-0.4 ms) six times in a row otherwise: test() of 13 824 points
     // 2.8 -> 2.0 ms.  GPIS_K4_SERIAL=1: one stream always.
-    if (!evfork_ && !side_off_) {
+    // (only while the pass is too small to fill the chip: on the 256^3 grid -- half a million tiles per launch -- launches that
+    // overlap take each other's LDS and run 2.3 % slower than one after the other)
+    int ntiles_pass = 0, nlaunch_pass = 0;
+    for (int c = 0; c < ONGPIS_NCLASS; ++c) { ntiles_pass += std::max(0, tot[c]); nlaunch_pass += tot[c] > 0; }
+    bool fork = !side_off_ && nlaunch_pass > 1 && ntiles_pass <= 8192;
+    if (fork && !evfork_) {
+        // (created by the first pass that forks, not before: every stream is a hardware queue)
         if (const char* e = getenv("GPIS_K4_SERIAL")) side_off_ = atoi(e) != 0;
         bool okc = !side_off_ && hipEventCreateWithFlags(&evfork_, hipEventDisableTiming) == hipSuccess;
         for (int i = 0; i < kSide && okc; ++i)
             okc = hipStreamCreateWithFlags(&side_[i], hipStreamNonBlocking) == hipSuccess && hipEventCreateWithFlags(&evjoin_[i], hipEventDisableTiming) == hipSuccess;
         if (!okc) { side_off_ = true; (void)hipGetLastError(); }
+        fork = !side_off_;
     }
-    // (only while the pass is too small to fill the chip: on the 256^3 grid -- half a million tiles per launch -- launches that
-    // overlap take each other's LDS and run 2.3 % slower than one after the other)
-    int ntiles_pass = 0, nlaunch_pass = 0;
-    for (int c = 0; c < ONGPIS_NCLASS; ++c) { ntiles_pass += std::max(0, tot[c]); nlaunch_pass += tot[c] > 0; }
-    const bool fork = !side_off_ && nlaunch_pass > 1 && ntiles_pass <= 8192;
     if (fork) GPIS_HIP(hipEventRecord(evfork_, s));
     int nlaunched = 0;
     bool used[kSide] = {false, false, false};

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 ROUND=${ROUND:-r03}; export ROUND
 mkdir -p gpurun_out
-CMD="bench.py --steps 1 --warmup 0 --cpu-sample 0 --stress 0 --no-host-api --update-repeats 1"   # (one fusion per accounting: with three or more, freed pool memory is being recycled in the background while K4 runs and 16 GB of foreign writes land in its counters)
+CMD="bench.py --steps 1 --warmup 0 --cpu-sample 0 --stress 0 --no-host-api --update-repeats 1"   # (one fusion per accounting: with three or more AND the side streams of small test() passes in use, rocprofv3 --pmc shows 0.65 GB of extra reads and writes per K4 launch -- profiles/README.md; run time is the same)
 OUT=gpurun_out/${ROUND}_k4_pmc.txt
 : > $OUT
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
