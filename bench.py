@@ -404,7 +404,7 @@ def main():
         # HBM bytes per K4 launch: rocprofv3 PMC passes of this command (tools/measure_traffic.sh), valid only for the
         # kernel source they were measured on
         traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_k4_traffic.json" % r) for r in ("r04", "r03", "r02")) if os.path.exists(q)), "")
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_k4_traffic.json" % r) for r in ("r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
         if tpath:
             with open(tpath) as fh:
                 tj = json.load(fh)

@@ -41,6 +41,8 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.gpis_device_count.restype = C.c_int
+    L.gpis_pool_cache_trim.restype = C.c_ulonglong
+    L.gpis_pool_cache_trim.argtypes = []
     L.gpis_version.restype = C.c_char_p
     L.gpis_set_device.argtypes = [C.c_int]
     L.gpis3_device.argtypes = [vp]
@@ -72,6 +74,7 @@ def lib():
     L.gpis3_sync.argtypes = [vp]
     L.gpis3_set_pipeline.argtypes = [vp, C.c_int]
     L.gpis3_set_host_gather.argtypes = [vp, C.c_int]
+    L.gpis3_set_keep_factors.argtypes = [vp, C.c_int]
     L.gpis2_create.restype = vp
     L.gpis2_destroy.argtypes = [vp]
     L.gpis2_reset.argtypes = [vp]
@@ -108,6 +111,24 @@ def lib():
     L.gpis3_set_lazy_inverse.argtypes = [vp, C.c_int]
     _lib = L
     return L
+
+
+def pool_cache_trim():
+    """Hand the device-pool chunks the library caches across maps back to the driver (gpis_pool_cache_trim); bytes released."""
+    return int(lib().gpis_pool_cache_trim()) if (_lib is not None or os.path.exists(LIB_PATH)) else 0
+
+
+def _trim_at_exit():
+    # only if the library was ever loaded: the cache holds memory of DESTROYED pools, nothing a live map uses
+    if _lib is not None:
+        try:
+            _lib.gpis_pool_cache_trim()
+        except Exception:
+            pass
+
+
+import atexit as _atexit  # noqa: E402
+_atexit.register(_trim_at_exit)
 
 
 def device_count():
@@ -250,11 +271,11 @@ class GPisMap3:
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def save(self, path):
-        """Map checkpoint: spatial index + surface points (gpis3_save)."""
+        """Map checkpoint: spatial index, surface points and the packed prediction records of the trained models (gpis3_save)."""
         _check(self.L.gpis3_save(self.h, os.fsencode(path)), "gpis3_save")
 
     def load(self, path):
-        """Replace the map's state with a checkpoint's and retrain its clusters (gpis3_load)."""
+        """Replace the map's state with a checkpoint's; models are restored verbatim, nothing is retrained (gpis3_load)."""
         _check(self.L.gpis3_load(self.h, os.fsencode(path)), "gpis3_load")
 
     def set_profile(self, on=True):
@@ -276,6 +297,10 @@ class GPisMap3:
 
     def set_host_gather(self, on=True):
         _check(self.L.gpis3_set_host_gather(self.h, int(on)), "gpis3_set_host_gather")
+
+    def set_keep_factors(self, on=True):
+        """Cross-check switch: keep the training side (factor, re-tiled factor) of every model after its inverse exists."""
+        _check(self.L.gpis3_set_keep_factors(self.h, int(on)), "gpis3_set_keep_factors")
 
 
 class GPisMap:

@@ -102,7 +102,7 @@ struct GPisMap3::Impl {
     OnGPISStore store;
     MapQuery mq;
     hipStream_t stream = nullptr;
-    // Pipelined update (opt-in: GPIS_PIPELINE_UPDATE=1 or gpis3_set_pipeline(map, 1); the default is the reference's
+    // Pipelined update (the default; GPIS_PIPELINE_UPDATE=0 or gpis3_set_pipeline(map, 0) select the reference's
     // synchronous update(), SURVEY 8(b) "Threading"): update() returns once the frame's OnGPIS training is ENQUEUED on
     // `train_stream`; the join -- wait, error word, dropped batch -- happens where the result is first needed: the next
     // update()'s updateGPs, test()/testDevice(), statistics, the sharded exchange, gpis3_sync().  The host work of the next
@@ -113,7 +113,7 @@ struct GPisMap3::Impl {
     bool batch_inflight = false, batch_launched = false;
     void launch_pixel_batch();
     bool pipeline = false;
-    bool device_gather = true;   // K6 range part on the device (GPIS_HOST_GATHER=1: the host walk, kept for the cross-check)
+    bool device_gather = true;   // K6 range part on the device (gpis3_set_host_gather: the host walk, kept for the cross-check)
     int finish_training();
     bool ok = false;        // device objects usable
     bool has_tree = false;  // reference: t != 0
@@ -175,13 +175,10 @@ struct GPisMap3::Impl {
         // update() is pipelined by default: it returns once the frame's training is enqueued; whatever needs the models (the
         // next training, test(), the getters, gpis3_sync) joins it.  GPIS_PIPELINE_UPDATE=0 / gpis3_set_pipeline(map, 0): every
         // update() joins its own training before it returns, like the reference's.
-        bool want_pipeline = true;
         if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) want_pipeline = atoi(e) != 0;
-        if (ok && want_pipeline) set_pipeline(true);
-        if (const char* e = getenv("GPIS_HOST_GATHER")) if (atoi(e) != 0) device_gather = false;
+        if (ok) apply_pipeline();
         if (const char* e = getenv("GPIS_EAGER_INVERSE")) if (atoi(e) != 0) store.lazy_inverse = false;
-        store.trim_scratch = true;     // a cluster keeps only what prediction reads once its inverse exists (GPIS_KEEP_FACTORS=1: keep all)
-        if (const char* e = getenv("GPIS_KEEP_FACTORS")) if (atoi(e) != 0) store.trim_scratch = false;
+        store.trim_scratch = true;     // a cluster keeps only what prediction reads once its inverse exists (gpis3_set_keep_factors: keep all)
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap3: no usable HIP device; update()/test() will fail\n");
     }
@@ -202,6 +199,11 @@ struct GPisMap3::Impl {
     // there (measured, tools/ubench/cumask_probe.hip: 6 us instead of 2 ms beside a busy unmasked stream).
     int pipeline_reserve = 32;
     bool pipeline_reserve_set = false;
+    // What the caller asked for (gpis3_set_pipeline / GPIS_PIPELINE_UPDATE) and what is in force: a map that shards its training over
+    // ranks or devices trains synchronously (every frame ends with the exchange) and sets no CUs aside, whatever was asked; the
+    // wish is remembered, so gpis3_set_shard(0, 1) restores it.
+    bool want_pipeline = true;
+    void apply_pipeline() { set_pipeline(want_pipeline && peers.empty() && shard_world == 1); }
     void set_pipeline(bool on) {
         (void)store.train_finish();
         int want = 0;
@@ -1011,8 +1013,8 @@ static GPisMap3::Impl* make_impl(const GPisMap3Param& par, const camParam& c, co
         for (int r = 1; r < world; ++r) { m->peers[r - 1]->impl()->shard_rank = r; m->peers[r - 1]->impl()->shard_world = world; }
         // several devices behind one map train synchronously (every frame ends with the model exchange): no CUs set aside
         if (world > 1) {
-            { DeviceScope ds(m->device); m->set_pipeline(false); }
-            for (GPisMap3* q : m->peers) { DeviceScope ds(q->impl()->device); q->impl()->set_pipeline(false); }
+            { DeviceScope ds(m->device); m->apply_pipeline(); }
+            for (GPisMap3* q : m->peers) { DeviceScope ds(q->impl()->device); q->impl()->apply_pipeline(); }
         }
     }
     return m;
@@ -1294,10 +1296,57 @@ struct CkptHeader {
     unsigned version, dim, sz_node, sz_point, sz_param;
     int root, has_tree;
     unsigned long long n_nodes, n_pts, n_free_nodes, n_free_pts, n_pending, n_models, model_bytes;
+    unsigned long long checksum;     // FNV-1a (64 bit) over every byte that follows the header
 };
-const char kCkptMagic[8] = {'G', 'P', 'I', 'S', '3', 'C', 'K', '1'};
-template <class T> bool wr_vec(FILE* f, const std::vector<T>& v) { return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size(); }
-template <class T> bool rd_vec(FILE* f, std::vector<T>& v, size_t n) { v.resize(n); return n == 0 || fread(v.data(), sizeof(T), n, f) == n; }
+const char kCkptMagic[8] = {'G', 'P', 'I', 'S', '3', 'C', 'K', '2'};
+constexpr unsigned kCkptVersion = 2;
+struct Fnv64 {
+    unsigned long long h = 1469598103934665603ull;
+    void add(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } }
+};
+template <class T> bool wr_vec(FILE* f, const std::vector<T>& v, Fnv64& ck) {
+    ck.add(v.data(), sizeof(T) * v.size());
+    return v.empty() || fwrite(v.data(), sizeof(T), v.size(), f) == v.size();
+}
+template <class T> bool rd_vec(FILE* f, std::vector<T>& v, size_t n, Fnv64& ck) {
+    v.resize(n);
+    if (n != 0 && fread(v.data(), sizeof(T), n, f) != n) return false;
+    ck.add(v.data(), sizeof(T) * n);
+    return true;
+}
+// The raw images of the tree are only swapped into the live map after every index in them has been checked: a file of the right
+// size with a damaged payload must be refused, not walked.  Checks: every child / parent / point / free-list index in
+// range; parent and child agree; live nodes are not on the free list and free entries are dead; a live leaf's point is alive;
+// the root is a live node without a parent; cluster cells with a model are live.
+bool ckpt_tree_consistent(const std::vector<FlatTree<3>::TNode>& nodes, const std::vector<FlatPoint<3>>& pts, const std::vector<int>& free_nodes,
+                          const std::vector<int>& free_pts, const std::vector<int>& pending, const std::vector<int>& cells, int root, bool has_tree) {
+    const int nn = (int)nodes.size(), np = (int)pts.size();
+    std::vector<char> node_free((size_t)nn, 0), pt_free((size_t)np, 0);
+    for (int i : free_nodes) { if (i < 0 || i >= nn || node_free[i] || nodes[i].alive) return false; node_free[i] = 1; }
+    for (int i : free_pts) { if (i < 0 || i >= np || pt_free[i] || pts[i].alive) return false; pt_free[i] = 1; }
+    for (int i : pending) { if (i < 0 || i >= np || pt_free[i] || pts[i].alive) return false; pt_free[i] = 1; }
+    for (int i = 0; i < nn; ++i) {
+        const FlatTree<3>::TNode& t = nodes[i];
+        if (!t.alive) continue;
+        if (t.par < -1 || t.par >= nn || t.pt < -1 || t.pt >= np) return false;
+        if (t.par >= 0) {
+            if (!nodes[t.par].alive || nodes[t.par].leaf) return false;
+            bool found = false;
+            for (int k = 0; k < FlatTree<3>::NC; ++k) found = found || nodes[t.par].ch[k] == i;
+            if (!found) return false;
+        }
+        if (t.pt >= 0 && !pts[t.pt].alive) return false;
+        for (int k = 0; k < FlatTree<3>::NC; ++k) {
+            const int c = t.ch[k];
+            if (c < -1 || c >= nn) return false;
+            if (!t.leaf && c >= 0 && (!nodes[c].alive || nodes[c].par != i)) return false;
+        }
+        if (!(t.h > 0.f)) return false;
+    }
+    if (has_tree && (root < 0 || root >= nn || !nodes[root].alive || nodes[root].par != -1)) return false;
+    for (int c : cells) if (c < 0 || c >= nn || !nodes[c].alive) return false;
+    return true;
+}
 }  // namespace
 
 bool GPisMap3::saveMap(const char* path) try {
@@ -1333,15 +1382,50 @@ bool GPisMap3::saveMap(const char* path) try {
     CkptHeader h;
     std::memset(&h, 0, sizeof(h));
     std::memcpy(h.magic, kCkptMagic, 8);
-    h.version = 1; h.dim = 3; h.sz_node = (unsigned)sizeof(FlatTree<3>::TNode); h.sz_point = (unsigned)sizeof(FlatPoint<3>); h.sz_param = (unsigned)sizeof(FlatTreeParam);
+    h.version = kCkptVersion; h.dim = 3; h.sz_node = (unsigned)sizeof(FlatTree<3>::TNode); h.sz_point = (unsigned)sizeof(FlatPoint<3>); h.sz_param = (unsigned)sizeof(FlatTreeParam);
     h.root = m.tree.root; h.has_tree = m.has_tree ? 1 : 0;
     h.n_nodes = m.tree.nodes.size(); h.n_pts = m.tree.pts.size(); h.n_free_nodes = m.tree.free_nodes.size();
     h.n_free_pts = m.tree.free_pts.size(); h.n_pending = m.tree.pending_free_pts.size();
     h.n_models = cells.size(); h.model_bytes = total;
-    bool ok = fwrite(&h, sizeof(h), 1, f) == 1 && fwrite(&m.tree.prm, sizeof(FlatTreeParam), 1, f) == 1 &&
-              wr_vec(f, m.tree.nodes) && wr_vec(f, m.tree.pts) && wr_vec(f, m.tree.free_nodes) && wr_vec(f, m.tree.free_pts) &&
-              wr_vec(f, m.tree.pending_free_pts) && wr_vec(f, cells) && wr_vec(f, offs) && wr_vec(f, bytes);
+    // images with the padding bytes of the structures zeroed (the same map always gives the same file) and the model slots,
+    // which mean nothing to another process, cleared
+    std::vector<FlatTree<3>::TNode> nimg(m.tree.nodes.size());
+    std::vector<FlatPoint<3>> pimg(m.tree.pts.size());
+    if (!nimg.empty()) std::memset((void*)nimg.data(), 0, sizeof(nimg[0]) * nimg.size());
+    if (!pimg.empty()) std::memset((void*)pimg.data(), 0, sizeof(pimg[0]) * pimg.size());
+    for (size_t i = 0; i < nimg.size(); ++i) {
+        const FlatTree<3>::TNode& a = m.tree.nodes[i];
+        FlatTree<3>::TNode& b = nimg[i];
+        for (int d = 0; d < 3; ++d) { b.c[d] = a.c[d]; b.lo[d] = a.lo[d]; b.hi[d] = a.hi[d]; }
+        b.h = a.h; b.hsq = a.hsq;
+        for (int k = 0; k < FlatTree<3>::NC; ++k) b.ch[k] = a.ch[k];
+        b.par = a.par; b.pt = a.pt; b.model = -1;
+        b.leaf = a.leaf; b.maxDepth = a.maxDepth; b.rootLimit = a.rootLimit; b.alive = a.alive;
+    }
+    for (size_t i = 0; i < pimg.size(); ++i) {
+        const FlatPoint<3>& a = m.tree.pts[i];
+        FlatPoint<3>& b = pimg[i];
+        for (int d = 0; d < 3; ++d) { b.pos[d] = a.pos[d]; b.grad[d] = a.grad[d]; }
+        b.val = a.val; b.sigx = a.sigx; b.sigg = a.sigg; b.type = a.type; b.alive = a.alive;
+    }
+    FlatTreeParam pimg_prm;
+    std::memset((void*)&pimg_prm, 0, sizeof(pimg_prm));
+    {
+        const FlatTreeParam& q = m.tree.prm;
+        pimg_prm.init_half = q.init_half; pimg_prm.min_half = q.min_half; pimg_prm.min_half_sq = q.min_half_sq; pimg_prm.max_half = q.max_half;
+        pimg_prm.cluster_half = q.cluster_half; pimg_prm.cluster_eps = q.cluster_eps; pimg_prm.qleaf_eps_plain = q.qleaf_eps_plain;
+        pimg_prm.qleaf_eps_dist = q.qleaf_eps_dist; pimg_prm.qdesc_eps = q.qdesc_eps;
+    }
+    Fnv64 ck;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;      // (rewritten below with the checksum)
+    ck.add(&pimg_prm, sizeof(pimg_prm));
+    ok = ok && fwrite(&pimg_prm, sizeof(FlatTreeParam), 1, f) == 1 &&
+         wr_vec(f, nimg, ck) && wr_vec(f, pimg, ck) && wr_vec(f, m.tree.free_nodes, ck) && wr_vec(f, m.tree.free_pts, ck) &&
+         wr_vec(f, m.tree.pending_free_pts, ck) && wr_vec(f, cells, ck) && wr_vec(f, offs, ck) && wr_vec(f, bytes, ck);
+    h.checksum = ck.h;
+    ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
+    if (!ok) (void)remove(path);      // never leave a half-written checkpoint behind
     return ok;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::saveMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::saveMap", "unknown exception"); return false; }
 
@@ -1363,11 +1447,14 @@ bool GPisMap3::loadMap_one(const char* path) try {
     struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
     CkptHeader h;
     FlatTreeParam prm;
-    if (fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != 1 || h.dim != 3 ||
+    Fnv64 ck;
+    if (fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != kCkptVersion || h.dim != 3 ||
         h.sz_node != sizeof(FlatTree<3>::TNode) || h.sz_point != sizeof(FlatPoint<3>) || h.sz_param != sizeof(FlatTreeParam)) return false;
     {   // another tree geometry (field by field: the struct has padding)
         const FlatTreeParam& q = m.tree.prm;
-        if (fread(&prm, sizeof(prm), 1, f) != 1 || prm.init_half != q.init_half || prm.min_half != q.min_half || prm.min_half_sq != q.min_half_sq ||
+        if (fread(&prm, sizeof(prm), 1, f) != 1) return false;
+        ck.add(&prm, sizeof(prm));
+        if (prm.init_half != q.init_half || prm.min_half != q.min_half || prm.min_half_sq != q.min_half_sq ||
             prm.max_half != q.max_half || prm.cluster_half != q.cluster_half || prm.cluster_eps != q.cluster_eps ||
             prm.qleaf_eps_plain != q.qleaf_eps_plain || prm.qleaf_eps_dist != q.qleaf_eps_dist || prm.qdesc_eps != q.qdesc_eps) return false;
     }
@@ -1377,34 +1464,50 @@ bool GPisMap3::loadMap_one(const char* path) try {
     std::vector<int> free_nodes, free_pts, pending, cells;
     std::vector<unsigned long long> offs;
     std::vector<char> bytes;
-    if (!rd_vec(f, nodes, (size_t)h.n_nodes) || !rd_vec(f, pts, (size_t)h.n_pts) || !rd_vec(f, free_nodes, (size_t)h.n_free_nodes) ||
-        !rd_vec(f, free_pts, (size_t)h.n_free_pts) || !rd_vec(f, pending, (size_t)h.n_pending) || !rd_vec(f, cells, (size_t)h.n_models) ||
-        !rd_vec(f, offs, (size_t)h.n_models + 1) || offs.back() != h.model_bytes || !rd_vec(f, bytes, (size_t)h.model_bytes)) return false;
-    if (h.has_tree && (h.root < 0 || (unsigned long long)h.root >= h.n_nodes)) return false;
-    for (int c : cells) if (c < 0 || (unsigned long long)c >= h.n_nodes) return false;
-    // the file is consistent: replace the map
+    if (!rd_vec(f, nodes, (size_t)h.n_nodes, ck) || !rd_vec(f, pts, (size_t)h.n_pts, ck) || !rd_vec(f, free_nodes, (size_t)h.n_free_nodes, ck) ||
+        !rd_vec(f, free_pts, (size_t)h.n_free_pts, ck) || !rd_vec(f, pending, (size_t)h.n_pending, ck) || !rd_vec(f, cells, (size_t)h.n_models, ck) ||
+        !rd_vec(f, offs, (size_t)h.n_models + 1, ck) || offs.back() != h.model_bytes || !rd_vec(f, bytes, (size_t)h.model_bytes, ck)) return false;
+    if (ck.h != h.checksum) return false;       // damaged payload
+    for (size_t i = 0; i + 1 < offs.size(); ++i) if (offs[i] > offs[i + 1]) return false;
+    if (!ckpt_tree_consistent(nodes, pts, free_nodes, free_pts, pending, cells, h.root, h.has_tree != 0)) return false;
+    // The file is consistent.  The models are unpacked into NEW slots of the live store first: until that has succeeded the map
+    // is untouched, and a failure releases what the call created (unpack_models) and leaves the map as it was.
     (void)m.finish_training();
+    std::vector<int> slots(cells.size(), -1);
+    if (!cells.empty()) {
+        int rc = GPIS_OK;
+        void* d_buf = nullptr;
+        if (hipMalloc(&d_buf, bytes.size()) != hipSuccess) rc = GPIS_ERR_HIP;
+        if (rc == GPIS_OK && hipMemcpy(d_buf, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) rc = GPIS_ERR_HIP;
+        std::vector<size_t> o(offs.begin(), offs.end());
+        if (rc == GPIS_OK) rc = m.store.unpack_models(d_buf, (int)cells.size(), 0, slots.data(), m.stream, o.data());
+        if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
+        if (d_buf) (void)hipFree(d_buf);
+        if (rc != GPIS_OK) {
+            for (int sl : slots) if (sl >= 0) m.store.release_slot(sl);
+            (void)hipGetLastError();
+            return false;
+        }
+    }
+    // replace the map: the old cells' models go back to the store one by one (the new ones live in the same store)
+    {
+        std::vector<int> old_cl;
+        if (m.has_tree) m.tree.all_clusters(old_cl);
+        for (int c : old_cl) if (m.tree.nodes[c].model >= 0) m.store.release_slot(m.tree.nodes[c].model);
+        for (int sl : m.tree.released_models) m.store.release_slot(sl);
+    }
     m.upd_rc = 0;
-    m.reset();
+    m.tree.clear(); m.has_tree = false;
+    m.gpo.reset_trained(); m.gpo_created = false;
+    m.obs_numdata = 0;
+    m.activeSet.clear();
     m.shard_jobs.clear(); m.table_pending = false;
     for (FlatTree<3>::TNode& t : nodes) t.model = -1;
     m.tree.nodes.swap(nodes); m.tree.pts.swap(pts); m.tree.free_nodes.swap(free_nodes); m.tree.free_pts.swap(free_pts);
     m.tree.pending_free_pts.swap(pending); m.tree.released_models.clear();
     m.tree.root = h.has_tree ? h.root : -1; m.tree.last_cell = -1;
     m.has_tree = h.has_tree != 0;
-    int rc = GPIS_OK;
-    if (!cells.empty()) {
-        void* d_buf = nullptr;
-        if (hipMalloc(&d_buf, bytes.size()) != hipSuccess) rc = GPIS_ERR_HIP;
-        if (rc == GPIS_OK && hipMemcpy(d_buf, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) rc = GPIS_ERR_HIP;
-        std::vector<int> slots(cells.size(), -1);
-        std::vector<size_t> o(offs.begin(), offs.end());
-        if (rc == GPIS_OK) rc = m.store.unpack_models(d_buf, (int)cells.size(), 0, slots.data(), m.stream, o.data());
-        if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
-        if (d_buf) (void)hipFree(d_buf);
-        if (rc == GPIS_OK) for (size_t i = 0; i < cells.size(); ++i) m.tree.nodes[cells[i]].model = slots[i];
-    }
-    if (rc != GPIS_OK) { m.upd_rc = rc; m.reset(); return false; }
+    for (size_t i = 0; i < cells.size(); ++i) m.tree.nodes[cells[i]].model = slots[i];
     m.build_cluster_table();
     return m.upd_rc == 0;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
@@ -1417,7 +1520,7 @@ int gpis3_impl_set_shard(GPisMap3* g, int rank, int world) {
     GPisMap3::Impl& m = *g->impl();
     if (m.table_pending) return GPIS_ERR_STATE;
     m.shard_rank = rank; m.shard_world = world;
-    if (world > 1 && m.pipeline) { DeviceScope ds(m.device); m.set_pipeline(false); }   // sharded training is synchronous: no CUs set aside
+    { DeviceScope ds(m.device); m.apply_pipeline(); }   // sharded training is synchronous (no CUs set aside); back at world 1 the caller's wish applies again
     return GPIS_OK;
 }
 int gpis3_impl_shard_info(GPisMap3* g, int* out, int n) {
@@ -1501,7 +1604,8 @@ void gpis3_impl_set_pipeline(GPisMap3* g, int on) {
     for (GPisMap3* q : m.peers) gpis3_impl_set_pipeline(q, on);
     DeviceScope ds(m.device);
     m.finish_training();
-    m.set_pipeline(on != 0);
+    m.want_pipeline = on != 0;
+    m.apply_pipeline();
 }
 // join the training in flight and compute the inverses it left to the first prediction; returns the update status
 int gpis3_impl_prepare_test(GPisMap3* g) {
@@ -1525,6 +1629,13 @@ void gpis3_impl_set_host_gather(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();
     for (GPisMap3* q : m.peers) gpis3_impl_set_host_gather(q, on);
     m.device_gather = on == 0;
+}
+void gpis3_impl_set_keep_factors(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_set_keep_factors(q, on);
+    DeviceScope ds(m.device);
+    m.finish_training();
+    m.store.trim_scratch = on == 0;
 }
 void gpis3_impl_profile(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

@@ -548,10 +548,16 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
     if (fork) GPIS_HIP(hipEventRecord(evfork_, s));
     int nlaunched = 0;
     bool used[kSide] = {false, false, false};
+    // (an error return inside the loop must not leave forked side streams un-joined to s: the caller's next work on s would
+    // race the launches already made)
+    auto join_sides = [&]() {
+        for (int i = 0; i < kSide; ++i)
+            if (used[i]) { (void)hipEventRecord(evjoin_[i], side_[i]); (void)hipStreamWaitEvent(s, evjoin_[i], 0); used[i] = false; }
+    };
     for (int c = ONGPIS_NCLASS - 1; c >= 0; --c) {
         int nt = tot[c];
         if (nt <= 0) continue;
-        if (tot[8 + c] + nt > tile_cap_) return GPIS_ERR_STATE;
+        if (tot[8 + c] + nt > tile_cap_) { join_sides(); return GPIS_ERR_STATE; }
         EvalArgs a;
         a.models = store.d_models(); a.xq = d_xq_;
         a.tile_model = t_model + tot[8 + c]; a.tile_off = t_off + tot[8 + c]; a.tile_cnt = t_cnt + tot[8 + c];
@@ -563,7 +569,7 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
             if (!used[i]) { GPIS_HIP(hipStreamWaitEvent(st, evfork_, 0)); used[i] = true; }
         }
         int rc = ongpis_eval_launch(c, nt, h_maxN_[c], h_maxLd_[c], a, st);
-        if (rc) return rc;
+        if (rc) { join_sides(); return rc; }
         ++nlaunched;
     }
     for (int i = 0; i < kSide; ++i)

@@ -35,13 +35,15 @@ struct DevPool {
 };
 // Standard-size chunks of destroyed pools are kept per device for the next pool of the process (a 512 MiB hipMalloc
 // costs milliseconds -- a map that is reset / re-created per sequence paid for its whole pool again, in the middle of its
-// first frames); bounded by GPIS_POOL_CACHE_GB (default 16, 0 = give everything back at once).
+// first frames); bounded by GPIS_POOL_CACHE_GB (default 4, 0 = give everything back at once).  gpis_pool_cache_trim() (C-ABI,
+// also run at process exit by the Python mirror) hands the cached chunks back to the driver; a hipMalloc of the library that
+// fails retries once after trimming the cache, so cached chunks never make an allocation of this library fail.
 namespace {
 constexpr size_t kPoolChunk = (size_t)512 << 20;
 std::mutex g_chunk_mu;
 std::map<int, std::vector<void*>> g_chunk_cache;     // device -> free standard-size chunks
 size_t chunk_cache_limit() {
-    static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 16.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
+    static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 4.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
     return lim;
 }
 void* chunk_cache_take() {
@@ -61,9 +63,21 @@ bool chunk_cache_put(int dev, void* c) {
     return true;
 }
 }  // namespace
+size_t pool_cache_trim() {
+    std::vector<std::pair<int, void*>> all;
+    {
+        std::lock_guard<std::mutex> lk(g_chunk_mu);
+        for (auto& kv : g_chunk_cache) { for (void* c : kv.second) all.push_back({kv.first, c}); kv.second.clear(); }
+    }
+    for (auto& dc : all) { DeviceScope ds(dc.first); (void)hipFree(dc.second); }
+    return all.size() * kPoolChunk;
+}
 DevPool* pool_create() { DevPool* p = new DevPool(); if (hipGetDevice(&p->device) != hipSuccess) p->device = -1; return p; }
 void pool_destroy(DevPool* p) {
     if (!p) return;
+    // (hipFree synchronises the device implicitly; a cached chunk skips it, so do it once, explicitly: nothing may still be
+    // running on memory that the next pool of the process hands out)
+    if (!p->chunks_.empty() && p->device >= 0) { DeviceScope ds(p->device); (void)hipDeviceSynchronize(); }
     for (size_t i = 0; i < p->chunks_.size(); ++i) {
         void* c = p->chunks_[i];
         if (!(p->chunk_sizes_[i] == kPoolChunk && p->device >= 0 && chunk_cache_put(p->device, c))) (void)hipFree(c);
@@ -77,7 +91,10 @@ void* pool_alloc(DevPool* p, size_t bytes) {
     if (it == p->free_size_.end()) {
         const size_t chunk = std::max(c, kChunk);
         void* base = (chunk == kChunk) ? chunk_cache_take() : nullptr;
-        if (!base && hipMalloc(&base, chunk) != hipSuccess) return nullptr;
+        if (!base && hipMalloc(&base, chunk) != hipSuccess) {
+            (void)hipGetLastError();
+            if (pool_cache_trim() == 0 || hipMalloc(&base, chunk) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        }
         p->chunks_.push_back(base);
         p->chunk_sizes_.push_back(chunk);
         p->chunk_base_.insert((char*)base);

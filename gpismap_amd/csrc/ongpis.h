@@ -213,8 +213,9 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
 int ongpis_coop_capacity();
-// A stream for training kernels: lowest priority; with reserve_cus > 0 restricted to the first (CUs - reserve_cus) bits of the CU
-// mask -- on gfx950 bit i is CU i / 8 of XCD i % 8, so every XCD keeps the same number of CUs and workgroup ids still go round
+// A stream for training kernels: reserve_cus == 0: non-blocking, lowest priority; reserve_cus > 0: restricted to the first
+// (CUs - reserve_cus) bits of the CU mask (such a stream is a DEFAULT-flag, normal-priority stream: HIP offers no masked creator
+// with flags; it is kept off the reserved CUs instead of being de-prioritised) -- on gfx950 bit i is CU i / 8 of XCD i % 8, so every XCD keeps the same number of CUs and workgroup ids still go round
 // the eight XCDs (tools/ubench/cumask_probe.hip).
 int ongpis_make_train_stream(hipStream_t* s, int reserve_cus);
 // K3b: explicit inverse of every factor of the batch, one wavefront per (job, block column); work = (job, column) pairs

@@ -61,6 +61,10 @@ int ongpis_make_train_stream(hipStream_t* s, int reserve_cus) {
     if (reserve_cus <= 0 || reserve_cus >= ncu) { GPIS_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr_least)); return GPIS_OK; }
     std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
     for (int i = 0; i < ncu - reserve_cus; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+    // (HIP has no creator that takes a CU mask AND flags / a priority: as far as the clr sources go, a masked stream is a
+    // hipStreamDefault stream -- it synchronises implicitly with the legacy NULL stream -- at normal priority.  The library itself
+    // never uses the NULL stream; a host process that does should set GPIS_PIPELINE_RESERVE_CUS=0 (ordinary non-blocking,
+    // lowest-priority training streams) or GPIS_PIPELINE_UPDATE=0: INTEGRATION.md "Pipelined update and the NULL stream".)
     if (hipExtStreamCreateWithCUMask(s, (uint32_t)mask.size(), mask.data()) != hipSuccess) {
         (void)hipGetLastError();      // (a device or runtime without CU masks: an ordinary lowest-priority stream -- the pipelined update still works, its ObsGP batches just wait for CUs)
         GPIS_HIP(hipStreamCreateWithPriority(s, hipStreamNonBlocking, pr_least));

@@ -35,13 +35,17 @@ namespace gpis {
 typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const int __attribute__((address_space(1))) * giptr;
 
-// Instrumented builds only (make EXTRA=-DGPIS_INSTRUMENT): per-workgroup cycle stamps, ongpis_test_instr.inc.  The
-// timing ablations of round 2 (wrong results by construction) are gone from the source; their findings are in DESIGN.md.
+// Instrumented builds only (make EXTRA=-DGPIS_INSTRUMENT): per-workgroup cycle stamps, ongpis_test_instr.inc.  No
+// wrong-result timing knobs live in this file (the round-2 / round-4 ablations are recorded in NOTEBOOK.md R4.2).
 #ifdef GPIS_INSTRUMENT
 #include "ongpis_test_instr.inc"
 #else
 #define K4_TRACE_DECL(A)
 #define K4_STAMP() do {} while (0)
+#define K4_LAP_START() do {} while (0)
+#define K4_LAP(i) do {} while (0)
+#define K4_LAP_COUNT(i) do {} while (0)
+#define K4_LAP_FLUSH() do {} while (0)
 #endif
 #ifndef K4_MINW
 #define K4_MINW (K4_QS == 1 ? 4 : 2)   // wavefronts per SIMD the register budget is cut for (128 / 256 VGPRs)
@@ -164,11 +168,8 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             cr = (KIND >= 0) ? KIND : ((info >> 28) & 0xF);
             xp = x4[p];
         }
-#ifndef K4_ABL_GENQ
-#define K4_ABL_GENQ 4     // (timing ablation: queries generated per lane; 4 = all)
-#endif
 #pragma unroll K4_GEN_UNROLL
-        for (int j = 0; j < K4_ABL_GENQ; ++j) {
+        for (int j = 0; j < 4; ++j) {
             const int q = 8 * qs + 4 * qh + j;
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (row < K && q < jcnt) {
@@ -202,10 +203,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         }
     };
     auto gen_tile = [&](int c, int qs, float* tbuf) {
-#ifdef K4_ABL_NOGEN      // (timing ablation only: wrong results.  CAUTION: the B tiles then hold constants, the matrix pipe draws less
-                         // power and the chip clocks higher -- most of the 8 % this "saves" is DVFS, not generation time: NOTEBOOK.md)
-        return;
-#endif
         const int r0 = c * 32, r1 = min(K, r0 + 32) - 1;
         const int k0 = row_type(r0), k1 = row_type(r1);
         if (k0 != k1) emit_rows(std::integral_constant<int, -1>(), c, qs, tbuf);
@@ -238,10 +235,6 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     };
 
     auto load_a = [&](float (&av)[16], int b, int c) {
-#ifdef K4_ABL_NOLOAD     // (timing ablation only: wrong results)
-        for (int g = 0; g < 16; ++g) av[g] = (float)(b + c + g);
-        return;
-#endif
         const int sbase = (b * (b + 1) / 2 + c) * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -318,8 +311,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[t][q][r] = 0.f;
 
+            K4_LAP_START();
             for (int ci = 0; ci < nch; ++ci, ++gci) {
                 if (WP == 0 && gen_first) produce_next();
+                K4_LAP(0);
                 {
                     if (K4_PRIO) __builtin_amdgcn_s_setprio(K4_PRIO);
                     const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
@@ -385,8 +380,12 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                     }
                 }
                 if (K4_PRIO) __builtin_amdgcn_s_setprio(0);
+                K4_LAP(1);
                 if (WP == 0 && !gen_first) produce_next();
+                K4_LAP(0);
                 __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
+                K4_LAP(2);
+                K4_LAP_COUNT(4);
             }
             // sums of squares of the finished rows; row K (block nbx-1: group 0, slot 0, wave 0) is the mean
 #pragma unroll
@@ -403,8 +402,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                         else ss[q] = fmaf(v, v, ss[q]);
                     }
             }
+            K4_LAP(3);
         }
     }
+    K4_LAP_FLUSH();
 
     K4_STAMP();
     // ---- reduce partials (lane halves, then waves in fixed order) ----
@@ -519,7 +520,7 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
 #endif
     hipLaunchKernelGGL(kern[use_table][kidx], dim3(ntiles), dim3(64 * W), lds, s, args);
 #ifdef GPIS_INSTRUMENT
-    k4_trace_dump(s);
+    k4_trace_dump(s, W, use_table, ntiles, maxN, maxLd, cb);
 #endif
     const hipError_t le = hipGetLastError();
     if (le != hipSuccess) {

@@ -87,9 +87,12 @@ public:
     bool test_one(float* x, int dim, int leng, float* res);
     bool testDevice(const float* d_x, int leng, float* d_res, void* hip_stream);
     void getAllNodes(std::vector<float>& out9);  /* pos3 grad3 val sigx sigg, tree order */
-    /* Map checkpoint (optional; the reference has none): the spatial index and the surface points with their
-     * data as one binary file.  loadMap() replaces the map (the camera stays) and retrains every cluster that holds points --
-     * the models are a function of the points, so test() answers with the same bits as before the save. */
+    /* Map checkpoint (optional; the reference has none): the spatial index, the surface points with their data and
+     * the trained models as PACKED PREDICTION RECORDS (row table, points, X = L^-1 with alpha: about 2 K^2 bytes per cluster), one
+     * binary file with a checksum over its payload.  loadMap() replaces the map (the camera stays) and restores the records
+     * verbatim -- nothing is retrained: the reference's update can leave a model stale, and a reloaded map must answer with
+     * the same bits as the saved one did.  Restored models are predict-only until their cluster is trained again.  A damaged or
+     * foreign file is refused and leaves the map as it was. */
     bool saveMap(const char* path);
     bool loadMap(const char* path);
     bool loadMap_one(const char* path);   /* this object's own device only */

@@ -32,6 +32,10 @@ typedef struct gpis_cam {  /* reference camParam, GPisMap3.h:29-46 */
 
 /* number of HIP devices visible (0 when no GPU: every compute entry then fails loudly) */
 int gpis_device_count(void);
+/* The library keeps the standard-size chunks of destroyed device pools per device for the next map of the process (bounded by
+ * GPIS_POOL_CACHE_GB, default 4).  gpis_pool_cache_trim() hands them back to the driver -- call it when another library in the
+ * process needs the memory; returns the bytes released.  No map may be in use on another thread during the call. */
+unsigned long long gpis_pool_cache_trim(void);
 const char* gpis_version(void);
 /* Device selection (one process per GPU in a multi-GPU job: call once with LOCAL_RANK before creating anything).
  * Every object created afterwards lives on the device current at its creation and makes it current inside each
@@ -95,9 +99,12 @@ int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 va
  * CUs the training streams leave free */
 int   gpis3_stats(void* map, double* out, int n);
 /* Map checkpoint (optional; the reference keeps its map only in the mex singleton): gpis3_save writes the spatial
- * index and the surface points with their data (GPisMap3::saveMap); gpis3_load replaces the map's state with a file's and
- * retrains every cluster that holds points -- same test() bits as before the save, and the next update continues from it.
- * The file is a raw image of this build's structures (refused by another build: GPIS_ERR_ARG); the camera is not part of it. */
+ * index, the surface points with their data and every trained model as its packed prediction record (about 2 K^2 bytes per
+ * cluster: the file of a 500-cluster map is ~1.2 GB) (GPisMap3::saveMap); gpis3_load replaces the map's state with a file's.
+ * Nothing is retrained -- the records are restored verbatim, so test() answers with the same bits as before the save and the
+ * next update continues from it; restored models are predict-only until their cluster is trained again.  The file is a raw image
+ * of this build's structures with a checksum over the payload: another build's, a truncated or a damaged file is refused
+ * (GPIS_ERR_ARG) and the map stays as it was.  The camera is not part of it. */
 int   gpis3_save(void* map, const char* path);
 int   gpis3_load(void* map, const char* path);
 int   gpis3_set_profile(void* map, int on);
@@ -111,9 +118,13 @@ int   gpis3_set_profile(void* map, int on);
  * exchange). */
 int   gpis3_sync(void* map);
 int   gpis3_set_pipeline(void* map, int on);
-/* K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device by
- * default; on != 0 (or GPIS_HOST_GATHER=1) selects the host walk it replaced -- same training sets, kept for the cross-check. */
+/* Cross-check paths, reachable through these setters only (no environment switch since round 5):
+ *  - K6's range part (which points of the touched cells lie in a cluster's range, GPisMap3.cpp:721-735) runs on the device;
+ *    gpis3_set_host_gather(map, 1) selects the host walk it replaced -- same training sets;
+ *  - a cluster keeps only what prediction reads once its inverse exists; gpis3_set_keep_factors(map, 1) keeps the training side
+ *    (factor, re-tiled factor) of every model as well (10 K^2 instead of 2 K^2 bytes per cluster). */
 int   gpis3_set_host_gather(void* map, int on);
+int   gpis3_set_keep_factors(void* map, int on);
 /* Lazy inverse at map level (default on; GPIS_EAGER_INVERSE=1 or gpis3_set_lazy_inverse(map, 0) turn it off): update() trains
  * factors and alpha; the explicit inverses are computed by the first test() after it (or by gpis3_prepare_test(), which also
  * joins a pipelined training) -- once per cluster, however many updates retrained it in between.  With a test() after

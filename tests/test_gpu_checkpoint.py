@@ -83,3 +83,32 @@ def test_checkpoint_into_a_map_over_two_logical_devices(tmp_path):
     a.update(replay.synthetic_depth(2), replay.IDENTITY_POSE)
     m.update(replay.synthetic_depth(2), replay.IDENTITY_POSE)
     assert np.array_equal(m.test(X), a.test(X), equal_nan=True)
+
+
+def test_damaged_payload_of_the_right_size_is_refused_and_files_are_deterministic(tmp_path):
+    """a checkpoint of the right size whose payload was overwritten must be refused (checksum + index validation),
+    never walked; two saves of the same map are the same bytes (no uninitialised padding in the file)."""
+    X = _grid(8)
+    a = gpismap_amd.GPisMap3()
+    for f in range(2):
+        a.update(replay.synthetic_depth(f), replay.IDENTITY_POSE)
+    ref = a.test(X).copy()
+    nodes = a.nodes().copy()
+    p1, p2 = tmp_path / "a.ckpt", tmp_path / "b.ckpt"
+    a.save(str(p1)); a.save(str(p2))
+    raw = p1.read_bytes()
+    assert raw == p2.read_bytes()
+    rng = np.random.default_rng(5)
+    for k in range(6):
+        b = bytearray(raw)
+        # damage the tree images (first part of the payload) and, in the later trials, anywhere in the file
+        lo, hi = (200, min(len(b), 200000)) if k < 3 else (128, len(b))
+        for pos in rng.integers(lo, hi, size=1 + 7 * (k % 3)):
+            b[int(pos)] ^= 0x5A
+        bad = tmp_path / ("bad%d.ckpt" % k)
+        bad.write_bytes(bytes(b))
+        with pytest.raises(gpismap_amd.GpisError):
+            a.load(str(bad))
+        assert np.array_equal(a.nodes(), nodes) and np.array_equal(a.test(X), ref, equal_nan=True)
+    a.load(str(p1))
+    assert np.array_equal(a.nodes(), nodes) and np.array_equal(a.test(X), ref, equal_nan=True)

@@ -1,34 +1,63 @@
 #!/usr/bin/env python3
-"""Summarise gpurun_out/k4_trace.txt (GPIS_K4_TRACE=<block> tools/k4_bench.py ...).
-Rows 0..W-1: per-wave phase stamps; rows W..2W-1: owner-path stamps of wave (row - W):
-per owned block [before A-operand wait, operands arrived, update done + diagonal tile landed, solved, published]."""
+"""Per-class cycle breakdown of K4 from gpurun_out/k4_trace.txt (instrumented build: EXTRA=-DGPIS_INSTRUMENT,
+gpismap_amd/csrc/ongpis_test_instr.inc).  One line per kernel class (wavefronts per workgroup, exp table or not): where the
+cycles of the sampled workgroups go, as a share of the workgroup's wave-cycles (sum over its wavefronts of start -> end):
+
+  stage   vectors + queries into LDS           exp     exp table                  first   first chunk(s) generated + barrier
+  gen     B-tile generation in the main loop   mma     X loads + matrix instrs    bar     barrier at the end of every chunk
+  ss      sums of squares per row group        tail    cross-wave reduce + store
+
+usage: tools/k4_trace_summary.py [trace.txt] [min_tiles]"""
+import collections
 import sys
-lines = open(sys.argv[1] if len(sys.argv) > 1 else 'gpurun_out/k4_trace.txt').read().split('\n')
-W = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-detail = int(sys.argv[3]) if len(sys.argv) > 3 else -1
-waves = {}; cur = None
-for l in lines:
-    if l.startswith('wave'):
-        cur = int(l.split()[1]); waves[cur] = []
-    elif l.strip():
-        waves[cur].append(int(l))
-for w in range(W):
-    ts = waves.get(w, [])
-    if len(ts) < 5:
-        continue
-    print('wave', w, 'events', len(ts), 'total cycles', ts[-1] - ts[0])
-    print('  stage0 %d  exp %d  bgen %d' % (ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2]))
-    steps = ts[4:-1] if (len(ts) - 5) % 4 == 0 else ts[4:]
-    n = len(steps) // 4
-    waitt = sum(steps[4 * i + 1] - steps[4 * i] for i in range(n)); own = sum(steps[4 * i + 2] - steps[4 * i + 1] for i in range(n))
-    gen = sum(steps[4 * i + 3] - steps[4 * i + 2] for i in range(n)); gap = sum(steps[4 * (i + 1)] - steps[4 * i + 3] for i in range(n - 1))
-    print('  steps %d: wait %d  owner(update+solve) %d  general updates %d  inter-step %d' % (n, waitt, own, gen, gap))
-    if w == detail:
-        for i in range(n):
-            print('    c=%d wait %d owner %d general %d' % (i, steps[4 * i + 1] - steps[4 * i], steps[4 * i + 2] - steps[4 * i + 1], steps[4 * i + 3] - steps[4 * i + 2]))
-    ev = waves.get(W + w, [])
-    if w == 0 and len(ev) >= 3:
-        print('  block 0: solve %d publish %d' % (ev[1] - ev[0], ev[2] - ev[1])); ev = ev[3:]
-    for i in range(len(ev) // 5):
-        e = ev[5 * i: 5 * i + 5]
-        print('  owned block %d (t=%d): operand wait %d  update %d  solve %d  publish %d' % (i, e[0], e[1] - e[0], e[2] - e[1], e[3] - e[2], e[4] - e[3]))
+
+
+def main():
+    path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/k4_trace.txt"
+    min_tiles = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    classes = collections.OrderedDict()
+    cur = None
+    for line in open(path):
+        t = line.split()
+        if not t:
+            continue
+        if t[0] == "launch":
+            d = dict(zip(t[1::2], map(int, t[2::2])))
+            cur = None
+            if d["tiles"] >= min_tiles:
+                cur = classes.setdefault((d["W"], d["table"]), dict(launches=0, tiles=0, maxLd=0, wg={}, seq=0))
+                cur["launches"] += 1; cur["tiles"] += d["tiles"]; cur["maxLd"] = max(cur["maxLd"], d["maxLd"]); cur["seq"] += 1
+        elif t[0] == "wg" and cur is not None:
+            wg, wave = int(t[1]), int(t[3])
+            st = list(map(int, t[5:13])); laps = list(map(int, t[14:19]))
+            cur["wg"].setdefault((cur["seq"], wg), {})[wave] = (st, laps)
+    print("%-18s %8s %9s %7s %10s | %6s %6s %6s | %6s %6s %6s %6s | %6s | %7s %s" %
+          ("class", "launches", "tiles", "maxK", "WG cycles", "stage", "exp", "first", "gen", "mma", "bar", "ss", "tail", "chunks", "slowest-wave mma share"))
+    for (W, table), c in classes.items():
+        tot = collections.Counter(); nwg = 0; wgc = 0.0; chunks = 0.0; crit = 0.0
+        for waves in c["wg"].values():
+            if not waves:
+                continue
+            nwg += 1
+            end = max(st[5] for st, _ in waves.values())
+            wgc += end
+            best = 0.0
+            for st, laps in waves.values():
+                tot["all"] += st[5]
+                tot["stage"] += st[1]; tot["exp"] += st[2] - st[1]; tot["first"] += st[3] - st[2]
+                tot["gen"] += laps[0]; tot["mma"] += laps[1]; tot["bar"] += laps[2]; tot["ss"] += laps[3]
+                tot["tail"] += st[5] - st[4]
+                chunks += laps[4]
+                best = max(best, laps[1] / max(1, st[5]))
+            crit += best
+        if not nwg:
+            continue
+        a = float(tot["all"]) or 1.0
+        pct = lambda k: 100.0 * tot[k] / a
+        print("W=%d %-13s %8d %9d %7d %10.0f | %5.1f%% %5.1f%% %5.1f%% | %5.1f%% %5.1f%% %5.1f%% %5.1f%% | %5.1f%% | %7.1f %5.1f%%   (%d workgroups sampled)" %
+              (W, "table" if table else "no table", c["launches"], c["tiles"], c["maxLd"] - 1, wgc / nwg, pct("stage"), pct("exp"), pct("first"),
+               pct("gen"), pct("mma"), pct("bar"), pct("ss"), pct("tail"), chunks / max(1, sum(len(w) for w in c["wg"].values())), 100.0 * crit / nwg, nwg))
+
+
+if __name__ == "__main__":
+    main()
