@@ -161,7 +161,7 @@ class GPisMap3:
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
                  "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK",
-                 "last_inverse_ms", "last_inverse_jobs", "exchange_bytes", "pipelined", "train_cu_reserve")
+                 "last_inverse_ms", "last_inverse_jobs", "exchange_bytes", "pipelined", "train_cu_reserve", "host_replays")
 
     def __init__(self, cam6=None, devices=None):
         """devices: list of HIP device ids for ONE map over several devices (gpis3_create_multi; a device may repeat:
@@ -266,8 +266,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 26)()
-        _check(self.L.gpis3_stats(self.h, a, 26), "gpis3_stats")
+        a = (C.c_double * 27)()
+        _check(self.L.gpis3_stats(self.h, a, 27), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def save(self, path):

@@ -155,6 +155,24 @@ struct GPisMap3::Impl {
     // per-query arithmetic does not depend on the cut, so the result is bit-identical to a single-device map.
     // (Reference: the fan-out inside the call over host threads, GPisMap3.cpp:759-784 and :904-949.)
     std::vector<GPisMap3*> peers;
+    // Round 5: the host logic of update() -- preprocessing, ObsGP regression and queries, the tree replay -- runs ONCE, on rank 0
+    // (the lead); the peers are device workers: the lead mirrors every slot operation on their stores, hands each its share of
+    // the frame's training jobs (point mirror + K6 on the worker's own device) and, after the exchange, its cluster table
+    // (built from the lead's tree).  A worker's own tree / ObsGP objects stay empty.
+    Impl* lead = nullptr;                        // workers: the rank-0 instance
+    int stat_host_replays = 0;                   // host replays (update_one executions) of the last update() call, all ranks
+    template <class F> void each_store(F f) {    // f(store) on this rank's store and on every worker's, each on its device
+        f(store);
+        for (GPisMap3* q : peers) { DeviceScope ds(q->impl()->device); f(q->impl()->store); }
+    }
+    int new_slot_all() {                         // the same slot id on every rank (the stores see the same sequence of operations)
+        const int s = store.new_slot();
+        for (GPisMap3* q : peers) {
+            DeviceScope ds(q->impl()->device);
+            if (q->impl()->store.new_slot() != s && !upd_rc) { upd_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] model slots of the devices diverged\n"); }
+        }
+        return s;
+    }
     void* d_send = nullptr; size_t cap_send = 0;
     void* d_recv = nullptr; size_t cap_recv = 0;
     float* h_xstage = nullptr; size_t cap_xstage = 0;     // multi-device test(): page-locked staging of this rank's query blocks ...
@@ -804,7 +822,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     auto join_previous = [&]() {
         finish_training();
         ulap("updateGPs: join");
-        for (int m : tree.released_models) store.release_slot(m);
+        for (int m : tree.released_models) each_store([&](OnGPISStore& st) { st.release_slot(m); });
         tree.released_models.clear();
     };
     if (updateSet.empty()) join_previous();
@@ -833,10 +851,10 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         }
         const size_t np_mirror = tree.pts.size();
         if (!device_gather) { join_previous(); rc = store.upload_points(mirror_soa.data(), (int)np_mirror, train_stream); }
+        std::vector<int> cr, desc, counts, cl_of;   // (device gather; kept for the workers' own K6 pass below)
+        int total = 0;
         if (rc == GPIS_OK && device_gather) {
             // K6 range part on the device: the host only names the cells (traversal order) and lists each touched cell once
-            std::vector<int> cr, desc, counts, cl_of;
-            int total = 0;
             for (int c : todo) {
                 const float h = tree.nodes[c].h * kRtimes;
                 const int e0 = (int)cr.size() / 2;
@@ -859,7 +877,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
             for (size_t i = 0; i < cl_of.size() && rc == GPIS_OK; ++i) {
                 if (counts[2 * i] == 0) continue;
                 const int c = cl_of[i];
-                if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
+                if (tree.nodes[c].model < 0) tree.nodes[c].model = new_slot_all();
                 TrainJob j;
                 j.model = tree.nodes[c].model; j.off = desc[8 * i + 2]; j.n = counts[2 * i]; j.ng = counts[2 * i + 1];
                 jobs.push_back(j);
@@ -875,7 +893,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     bool tiny = ((double)std::fabs(p.grad[0]) < 1e-6) && ((double)std::fabs(p.grad[1]) < 1e-6) && ((double)std::fabs(p.grad[2]) < 1e-6);
                     if (!(((double)p.sigg > 0.1001) || tiny)) ++ng;
                 }
-                if (tree.nodes[c].model < 0) tree.nodes[c].model = store.new_slot();
+                if (tree.nodes[c].model < 0) tree.nodes[c].model = new_slot_all();
                 TrainJob j;
                 j.model = tree.nodes[c].model; j.off = (int)ids.size(); j.n = (int)res.size(); j.ng = ng;
                 jobs.push_back(j);
@@ -904,7 +922,35 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     shard_jobs.push_back({jobs[j].model, jobs[j].n, jobs[j].ng, owner[j]});
                     if (owner[j] == shard_rank) mine.push_back(jobs[j]);
                 }
-                if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
+                if (!peers.empty()) {
+                    // Lead mode: every worker gets the point mirror, runs the K6 range pass on its own device (same cell lists, same
+                    // offsets: its id buffer then holds what the lead's holds) and trains its share -- each on its own host thread,
+                    // beside the lead's share.
+                    std::vector<int> wrc(1 + peers.size(), GPIS_OK);
+                    std::vector<std::thread> th;
+                    for (size_t r = 1; r <= peers.size(); ++r)
+                        th.emplace_back([&, r] {
+                            Impl& w = *peers[r - 1]->impl();
+                            DeviceScope ds(w.device);
+                            w.shard_jobs = shard_jobs; w.table_pending = true; w.has_tree = true; w.upd_rc = 0;
+                            if (rc != GPIS_OK) return;
+                            std::vector<TrainJob> wj;
+                            for (size_t j = 0; j < jobs.size(); ++j) if (owner[j] == (int)r) wj.push_back(jobs[j]);
+                            int q = w.store.upload_points(mirror_soa.data(), (int)np_mirror, w.train_stream);
+                            if (q == GPIS_OK && device_gather && !cl_of.empty()) {
+                                std::vector<int> wcounts(counts.size(), 0);
+                                q = w.store.gather_ranges(cell_lists.pts.data(), (int)cell_lists.pts.size(), cr.data(), (int)cr.size() / 2, desc.data(),
+                                                          (int)cl_of.size(), total, wcounts.data(), w.train_stream);
+                                if (q == GPIS_OK && wcounts != counts) q = GPIS_ERR_STATE;
+                            }
+                            if (q == GPIS_OK && !wj.empty()) q = device_gather ? w.store.train_batch_dev(wj, w.train_stream) : w.store.train_batch(wj, ids, w.train_stream);
+                            wrc[r] = q;
+                            if (q != GPIS_OK) w.upd_rc = q;
+                        });
+                    if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
+                    for (auto& t : th) t.join();
+                    for (size_t r = 1; r < wrc.size(); ++r) if (wrc[r] != GPIS_OK && rc == GPIS_OK) rc = wrc[r];
+                } else if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
                 table_pending = true;
             } else if (rc == GPIS_OK) rc = train(jobs);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
@@ -913,7 +959,11 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         }
     }
     activeSet.clear();
-    if (!table_pending) build_cluster_table();
+    if (!table_pending) {
+        build_cluster_table();
+        // (nothing was trained, but cells may have come or gone: the workers' tables follow the lead's index too)
+        for (GPisMap3* q : peers) { Impl& w = *q->impl(); DeviceScope ds(w.device); w.has_tree = true; w.build_cluster_table(); if (w.upd_rc && !upd_rc) upd_rc = w.upd_rc; }
+    }
     ulap("updateGPs: cluster table");
 }
 
@@ -930,6 +980,7 @@ int GPisMap3::Impl::finish_training() {
 
 void GPisMap3::Impl::build_cluster_table() {
     table_pending = false;
+    const T3& tree = lead ? lead->tree : this->tree;    // (a device worker answers test() from the lead's index; its model slots are the lead's)
 
     // cluster table for test(): every non-empty cluster cell in traversal order
     std::vector<int> cl;
@@ -1010,7 +1061,7 @@ static GPisMap3::Impl* make_impl(const GPisMap3Param& par, const camParam& c, co
         }
         const int world = 1 + (int)m->peers.size();
         m->shard_rank = 0; m->shard_world = world;
-        for (int r = 1; r < world; ++r) { m->peers[r - 1]->impl()->shard_rank = r; m->peers[r - 1]->impl()->shard_world = world; }
+        for (int r = 1; r < world; ++r) { m->peers[r - 1]->impl()->shard_rank = r; m->peers[r - 1]->impl()->shard_world = world; m->peers[r - 1]->impl()->lead = m; }
         // several devices behind one map train synchronously (every frame ends with the model exchange): no CUs set aside
         if (world > 1) {
             { DeviceScope ds(m->device); m->apply_pipeline(); }
@@ -1126,8 +1177,10 @@ static int exchange_models_multi(GPisMap3* self) {
 
 void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) try {  // GPisMap3.cpp:218-237
     if (p_->peers.empty() || p_->shard_rank != 0) { update_one(dataz, N, pose); return; }
-    // several devices: the same update on every rank (own host thread), then the exchange of the trained models
-    for_each_rank(*p_, [&](int r, GPisMap3* q) { if (r == 0) update_one(dataz, N, pose); else q->update_one(dataz, N, pose); });
+    // several devices: the host logic runs once, here (the lead); updateGPs hands the workers their shares of the training, then
+    // the trained models are exchanged and every rank builds its cluster table from the lead's index
+    for (GPisMap3* q : p_->peers) { Impl& w = *q->impl(); w.upd_rc = 0; w.shard_jobs.clear(); w.table_pending = false; w.stat_host_replays = 0; }
+    update_one(dataz, N, pose);
     int rc = p_->upd_rc;
     for (GPisMap3* q : p_->peers) if (!rc) rc = q->impl()->upd_rc;
     if (!rc && p_->table_pending) rc = exchange_models_multi(this);
@@ -1138,6 +1191,7 @@ void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
     m.upd_rc = 0;
+    m.stat_host_replays = 1;
     m.shard_jobs.clear();       // an update that returns early (no valid pixel, failed regression) must not leave the
     m.table_pending = false;    // previous frame's job list to a later exchange
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
@@ -1432,8 +1486,10 @@ bool GPisMap3::saveMap(const char* path) try {
 bool GPisMap3::loadMap(const char* path) try {
     if (p_->peers.empty() || p_->shard_rank != 0) return loadMap_one(path);
     // several devices behind one map: every device keeps a full copy of the models -- each rank loads the file
-    std::vector<int> okv(1 + p_->peers.size(), 0);
-    for_each_rank(*p_, [&](int r, GPisMap3* q) { okv[r] = (r == 0 ? loadMap_one(path) : q->loadMap_one(path)) ? 1 : 0; });
+    // (the lead first: the workers build their cluster tables from ITS index)
+    if (!loadMap_one(path)) return false;
+    std::vector<int> okv(1 + p_->peers.size(), 1);
+    for_each_rank(*p_, [&](int r, GPisMap3* q) { if (r > 0) okv[r] = q->loadMap_one(path) ? 1 : 0; });
     for (int v : okv) if (!v) return false;
     return true;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
@@ -1473,6 +1529,7 @@ bool GPisMap3::loadMap_one(const char* path) try {
     // The file is consistent.  The models are unpacked into NEW slots of the live store first: until that has succeeded the map
     // is untouched, and a failure releases what the call created (unpack_models) and leaves the map as it was.
     (void)m.finish_training();
+    const std::vector<int> old_slots = m.store.live_slots();
     std::vector<int> slots(cells.size(), -1);
     if (!cells.empty()) {
         int rc = GPIS_OK;
@@ -1489,13 +1546,9 @@ bool GPisMap3::loadMap_one(const char* path) try {
             return false;
         }
     }
-    // replace the map: the old cells' models go back to the store one by one (the new ones live in the same store)
-    {
-        std::vector<int> old_cl;
-        if (m.has_tree) m.tree.all_clusters(old_cl);
-        for (int c : old_cl) if (m.tree.nodes[c].model >= 0) m.store.release_slot(m.tree.nodes[c].model);
-        for (int sl : m.tree.released_models) m.store.release_slot(sl);
-    }
+    // replace the map: the models the store held before the call go back to it one by one (the new ones live in the same store;
+    // by slot, not by walking the tree: a device worker's models hang off the lead's tree)
+    for (int sl : old_slots) m.store.release_slot(sl);
     m.upd_rc = 0;
     m.tree.clear(); m.has_tree = false;
     m.gpo.reset_trained(); m.gpo_created = false;
@@ -1581,15 +1634,17 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     m.finish_training();      // (the training time of the last batch is read off its events)
-    double v[26] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[27] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
                     m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK,
                     (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs, m.stat_exchange_bytes,
-                    m.pipeline ? 1.0 : 0.0, (double)m.store.cu_reserve()};
-    for (int i = 0; i < n && i < 26; ++i) out[i] = v[i];
+                    m.pipeline ? 1.0 : 0.0, (double)m.store.cu_reserve(), 0.0};
+    v[26] = (double)m.stat_host_replays;
+    for (GPisMap3* q : m.peers) v[26] += (double)q->impl()->stat_host_replays;
+    for (int i = 0; i < n && i < 27; ++i) out[i] = v[i];
 }
 // join the training the last update() left in flight; returns the update status (0: fine)
 int gpis3_impl_sync(GPisMap3* g) {

@@ -94,6 +94,7 @@ public:
     ClusterModel* d_models() { return d_models_; }   // device array mirroring models_
     int sync_models(hipStream_t s);                  // re-upload descriptor table if dirty
     int num_slots() const { return (int)models_.size(); }
+    std::vector<int> live_slots() const { std::vector<int> v; for (int i = 0; i < (int)models_.size(); ++i) if (live_[i]) v.push_back(i); return v; }
     size_t device_bytes() const;
     DevPool* pool() { return pool_; }
     // timing of the dominant kernels (hipEvents on the launch stream), ms of the last call

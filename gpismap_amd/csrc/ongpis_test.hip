@@ -295,6 +295,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         int gci = 0;
         for (int g = 0; g < ngroups; ++g) {
             // this wave's block rows in group g: slot t holds the (g RG + t WC + q)-th largest row, q snaking with t
+            // (Round 5: pairing complementary rows q / 7 - q on the two wavefronts of a SIMD -- every SIMD then carries the same number
+            // of products in every chunk -- measured 0.7 % SLOWER on the bench and 4 points slower at K = 1598: a wavefront left alone on
+            // its SIMD with seven products does not hide its own X-tile loads.  The row table also fixes the order of the variance sums
+            // (oracle reduce_ss), so it is not free to change.  NOTEBOOK R5.2.)
             int brow[NBW];
 #pragma unroll
             for (int t = 0; t < NBW; ++t) {

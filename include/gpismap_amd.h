@@ -91,12 +91,13 @@ int   gpis3_shard_finish(void* map);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
-/* out[0..25]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
+/* out[0..26]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
  * GP evaluations of last test, ms in K4 of last test (profiling on), device bytes, algorithmic flops of last test, K4 launches,
  * ms in K6+K3+K3b of last update (profiling on), model bytes, update phases ms [preproc, ObsGP train, re-evaluation,
  * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch, ms and clusters of the
  * last deferred inverse pass (profiling on), bytes received in the last in-library model exchange, pipelined update on (0/1),
- * CUs the training streams leave free */
+ * CUs the training streams leave free, host replays of the last update() over all devices of the map (1: the host logic ran
+ * once, on the lead device, however many devices train) */
 int   gpis3_stats(void* map, double* out, int n);
 /* Map checkpoint (optional; the reference keeps its map only in the mex singleton): gpis3_save writes the spatial
  * index, the surface points with their data and every trained model as its packed prediction record (about 2 K^2 bytes per

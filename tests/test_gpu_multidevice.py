@@ -30,6 +30,8 @@ def test_multi_device_map_equals_single_device_map(devices):
         assert np.array_equal(one.nodes(), many.nodes())
         # the model exchange moved the other ranks' records at their own sizes and nothing else
         assert many.stats()["exchange_bytes"] == sum(many.shard_bytes(r) for r in range(1, len(devices)))
+        # the host logic (preprocessing, ObsGP, tree replay) ran ONCE for the whole map, on the lead device
+        assert many.stats()["host_replays"] == 1 and one.stats()["host_replays"] == 1
         a, b = one.test(grid), many.test(grid)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), i
     many.reset()

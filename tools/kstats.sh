@@ -8,5 +8,6 @@ rm -rf /tmp/kst
 rocprofv3 --kernel-trace --stats -d /tmp/kst -o k -- python3 "$@" > /tmp/kst.log 2>&1
 db=$(find /tmp/kst -name "*.db" | head -1)
 python3 profiles/summarize_rocpd.py "$db" > "$out"
-tail -3 /tmp/kst.log >> "$out"
+grep '^{"metric"' /tmp/kst.log | tail -1 >> "$out"     # (the bench line of the profiled run, when the command was bench.py)
+tail -3 /tmp/kst.log | grep -v "^{" >> "$out"
 cat "$out"
