@@ -75,6 +75,7 @@ def lib():
     L.gpis3_set_pipeline.argtypes = [vp, C.c_int]
     L.gpis3_set_host_gather.argtypes = [vp, C.c_int]
     L.gpis3_set_keep_factors.argtypes = [vp, C.c_int]
+    L.gpis3_set_shard_factors.argtypes = [vp, C.c_int]
     L.gpis2_create.restype = vp
     L.gpis2_destroy.argtypes = [vp]
     L.gpis2_reset.argtypes = [vp]
@@ -161,7 +162,7 @@ class GPisMap3:
                  "last_test_evals", "last_test_k4_ms", "device_bytes", "last_test_flops", "last_test_k4_launches",
                  "last_train_ms", "model_bytes", "upd_preproc_ms", "upd_obsgp_train_ms", "upd_reeval_ms", "upd_eval_ms",
                  "upd_gps_ms", "last_train_flops", "last_train_bytes", "last_train_jobs", "last_train_maxK",
-                 "last_inverse_ms", "last_inverse_jobs", "exchange_bytes", "pipelined", "train_cu_reserve", "host_replays")
+                 "last_inverse_ms", "last_inverse_jobs", "exchange_bytes", "pipelined", "train_cu_reserve", "host_replays", "deferred_inverses")
 
     def __init__(self, cam6=None, devices=None):
         """devices: list of HIP device ids for ONE map over several devices (gpis3_create_multi; a device may repeat:
@@ -266,8 +267,8 @@ class GPisMap3:
         return out
 
     def stats(self):
-        a = (C.c_double * 27)()
-        _check(self.L.gpis3_stats(self.h, a, 27), "gpis3_stats")
+        a = (C.c_double * 28)()
+        _check(self.L.gpis3_stats(self.h, a, 28), "gpis3_stats")
         return dict(zip(self.STAT_KEYS, list(a)))
 
     def save(self, path):
@@ -297,6 +298,10 @@ class GPisMap3:
 
     def set_host_gather(self, on=True):
         _check(self.L.gpis3_set_host_gather(self.h, int(on)), "gpis3_set_host_gather")
+
+    def set_shard_factors(self, mode=-1):
+        """Records of a sharded update: 1 factor records (receivers invert lazily), 0 prediction records, -1 follow the inverse mode."""
+        _check(self.L.gpis3_set_shard_factors(self.h, int(mode)), "gpis3_set_shard_factors")
 
     def set_keep_factors(self, on=True):
         """Cross-check switch: keep the training side (factor, re-tiled factor) of every model after its inverse exists."""

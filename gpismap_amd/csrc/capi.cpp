@@ -22,6 +22,7 @@ int gpis3_impl_sync(GPisMap3* m);
 void gpis3_impl_set_pipeline(GPisMap3* m, int on);
 void gpis3_impl_set_host_gather(GPisMap3* m, int on);
 void gpis3_impl_set_keep_factors(GPisMap3* m, int on);
+void gpis3_impl_set_shard_factors(GPisMap3* m, int mode);
 int gpis3_impl_prepare_test(GPisMap3* m);
 void gpis3_impl_set_lazy_inverse(GPisMap3* m, int on);
 int gpis2_impl_update_fail(GPisMap* m);
@@ -148,6 +149,7 @@ int gpis3_stats(void* m, double* out, int n) { if (!m || !out) return GPIS_ERR_A
 int gpis3_sync(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_sync((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_pipeline(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis3_impl_set_pipeline((GPisMap3*)m, on); return GPIS_OK; } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_host_gather(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_host_gather((GPisMap3*)m, on); return GPIS_OK; }
+int gpis3_set_shard_factors(void* m, int mode) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_shard_factors((GPisMap3*)m, mode); return GPIS_OK; }
 int gpis3_set_keep_factors(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis3_impl_set_keep_factors((GPisMap3*)m, on); return GPIS_OK; } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_prepare_test(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_prepare_test((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
 int gpis3_set_lazy_inverse(void* m, int on) { if (!m) return GPIS_ERR_ARG; gpis3_impl_set_lazy_inverse((GPisMap3*)m, on); return GPIS_OK; }

@@ -159,6 +159,12 @@ struct GPisMap3::Impl {
     // (the lead); the peers are device workers: the lead mirrors every slot operation on their stores, hands each its share of
     // the frame's training jobs (point mirror + K6 on the worker's own device) and, after the exchange, its cluster table
     // (built from the lead's tree).  A worker's own tree / ObsGP objects stay empty.
+    // What travels in the model exchange of a sharded update: -1 (default) follows the inverse mode -- with the lazy inverse the
+    // owner ships FACTOR records (model_pack.hip kind 1: Lt + alpha, the same bytes) and every receiver inverts what it predicts
+    // with, when it predicts; with the eager inverse, prediction records (X).  0 / 1 force one or the other (gpis3_set_shard_factors).
+    int shard_factors_mode = -1;
+    bool ship_factors() const { return shard_factors_mode < 0 ? store.lazy_inverse : shard_factors_mode != 0; }
+    int stat_deferred_inverses = 0;              // factor records this rank received in the last exchange (their X is still to come)
     Impl* lead = nullptr;                        // workers: the rank-0 instance
     int stat_host_replays = 0;                   // host replays (update_one executions) of the last update() call, all ranks
     template <class F> void each_store(F f) {    // f(store) on this rank's store and on every worker's, each on its device
@@ -1179,7 +1185,7 @@ void GPisMap3::update(float* dataz, int N, std::vector<float>& pose) try {  // G
     if (p_->peers.empty() || p_->shard_rank != 0) { update_one(dataz, N, pose); return; }
     // several devices: the host logic runs once, here (the lead); updateGPs hands the workers their shares of the training, then
     // the trained models are exchanged and every rank builds its cluster table from the lead's index
-    for (GPisMap3* q : p_->peers) { Impl& w = *q->impl(); w.upd_rc = 0; w.shard_jobs.clear(); w.table_pending = false; w.stat_host_replays = 0; }
+    for (GPisMap3* q : p_->peers) { Impl& w = *q->impl(); w.upd_rc = 0; w.shard_jobs.clear(); w.table_pending = false; w.stat_host_replays = 0; w.stat_deferred_inverses = 0; }
     update_one(dataz, N, pose);
     int rc = p_->upd_rc;
     for (GPisMap3* q : p_->peers) if (!rc) rc = q->impl()->upd_rc;
@@ -1192,6 +1198,7 @@ void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     Impl& m = *p_;
     m.upd_rc = 0;
     m.stat_host_replays = 1;
+    m.stat_deferred_inverses = 0;
     m.shard_jobs.clear();       // an update that returns early (no valid pixel, failed regression) must not leave the
     m.table_pending = false;    // previous frame's job list to a later exchange
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
@@ -1609,7 +1616,7 @@ int gpis3_impl_shard_pack(GPisMap3* g, void* d_buf, void* stream) {
     shard_layout(m, m.shard_rank, slots, offs);
     if (slots.empty()) return GPIS_OK;
     if (!d_buf) return GPIS_ERR_ARG;
-    return m.store.pack_models(slots.data(), (int)slots.size(), d_buf, 0, stream ? (hipStream_t)stream : m.stream, offs.data());
+    return m.store.pack_models(slots.data(), (int)slots.size(), d_buf, 0, stream ? (hipStream_t)stream : m.stream, offs.data(), m.ship_factors());
 }
 int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, void* stream) {
     GPisMap3::Impl& m = *g->impl();
@@ -1619,7 +1626,9 @@ int gpis3_impl_shard_unpack(GPisMap3* g, int owner, const void* d_buf, void* str
     shard_layout(m, owner, slots, offs);
     if (slots.empty()) return GPIS_OK;
     if (!d_buf) return GPIS_ERR_ARG;
-    return m.store.unpack_models(d_buf, (int)slots.size(), 0, slots.data(), stream ? (hipStream_t)stream : m.stream, offs.data());
+    const int rc = m.store.unpack_models(d_buf, (int)slots.size(), 0, slots.data(), stream ? (hipStream_t)stream : m.stream, offs.data());
+    if (rc == GPIS_OK) m.stat_deferred_inverses += m.store.last_unpack_factors;
+    return rc;
 }
 int gpis3_impl_shard_finish(GPisMap3* g) {
     GPisMap3::Impl& m = *g->impl();
@@ -1634,17 +1643,17 @@ void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);
     m.finish_training();      // (the training time of the last batch is read off its events)
-    double v[27] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
+    double v[28] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,
                     (double)m.store.last_train_ms, (double)m.stat_model_bytes,
                     m.last_update_ms[0], m.last_update_ms[1], m.last_update_ms[2], m.last_update_ms[3], m.last_update_ms[4],
                     m.store.last_train_flops, m.store.last_train_bytes, (double)m.store.last_train_jobs, (double)m.store.last_train_maxK,
                     (double)m.store.last_inverse_ms, (double)m.store.last_inverse_jobs, m.stat_exchange_bytes,
-                    m.pipeline ? 1.0 : 0.0, (double)m.store.cu_reserve(), 0.0};
+                    m.pipeline ? 1.0 : 0.0, (double)m.store.cu_reserve(), 0.0, (double)m.stat_deferred_inverses};
     v[26] = (double)m.stat_host_replays;
     for (GPisMap3* q : m.peers) v[26] += (double)q->impl()->stat_host_replays;
-    for (int i = 0; i < n && i < 27; ++i) out[i] = v[i];
+    for (int i = 0; i < n && i < 28; ++i) out[i] = v[i];
 }
 // join the training the last update() left in flight; returns the update status (0: fine)
 int gpis3_impl_sync(GPisMap3* g) {
@@ -1684,6 +1693,11 @@ void gpis3_impl_set_host_gather(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();
     for (GPisMap3* q : m.peers) gpis3_impl_set_host_gather(q, on);
     m.device_gather = on == 0;
+}
+void gpis3_impl_set_shard_factors(GPisMap3* g, int mode) {
+    GPisMap3::Impl& m = *g->impl();
+    for (GPisMap3* q : m.peers) gpis3_impl_set_shard_factors(q, mode);
+    m.shard_factors_mode = mode < 0 ? -1 : (mode != 0);
 }
 void gpis3_impl_set_keep_factors(GPisMap3* g, int on) {
     GPisMap3::Impl& m = *g->impl();

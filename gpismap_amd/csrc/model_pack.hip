@@ -6,9 +6,14 @@
 // counterpart (single process).
 //
 // Record layout:
-//   [0, 64)      header: int dim, N, ng, K, ld, nb; float scale; int reserved[9]
-//   [64, ..)     rowinfo[ld] (int)  |  x4[N][4] (float)  |  Xt tiles [ld/32 (ld/32 + 1) / 2][1024] (float), each piece 256-B aligned
-// Only what K4 reads is shipped (Xt carries alpha in row K): 2 K^2 + 20 K bytes instead of the 10 K^2 of a trained model.
+//   [0, 64)      header: int dim, N, ng, K, ld, nb; float scale; int kind; int reserved[8]
+//   [64, ..)     rowinfo[ld] (int)  |  x4[N][4] (float)  |  tiles [ld/32 (ld/32 + 1) / 2][1024] (float)  |  alpha[ld] (float), each piece 256-B aligned
+// kind 0 (prediction record): the tiles are Xt -- only what K4 reads is shipped (Xt carries alpha in row K): 2 K^2 + 24 K bytes instead
+// of the 10 K^2 of a trained model; the alpha piece is unused.
+// kind 1 (factor record, round 5): the tiles are Lt (-L re-tiled, inverted diagonal blocks) and alpha travels beside them -- the same
+// bytes; the receiver computes X = L^-1 itself (K3b) when it first predicts with the model, so a sharded update() keeps the lazy
+// inverse: a cluster retrained in several consecutive updates is never inverted in between, on any rank.  Every record has the
+// same size whatever its kind: every rank can still lay out every rank's buffer from (ld, N) alone.
 #include "ongpis.h"
 
 namespace gpis {
@@ -17,39 +22,48 @@ __host__ __device__ inline size_t pk_align(size_t v) { return (v + 255) & ~(size
 __host__ __device__ inline size_t pk_off_ri() { return 64; }
 __host__ __device__ inline size_t pk_off_x4(int ld) { return pk_align(64 + sizeof(int) * (size_t)ld); }
 __host__ __device__ inline size_t pk_off_xt(int ld, int N) { return pk_align(pk_off_x4(ld) + 16 * (size_t)N); }
-__host__ __device__ inline size_t pk_bytes(int ld, int N) {
+__host__ __device__ inline size_t pk_off_alpha(int ld, int N) {
     const size_t nbx = ld / 32;
     return pk_align(pk_off_xt(ld, N) + sizeof(float) * 1024 * nbx * (nbx + 1) / 2);
 }
+__host__ __device__ inline size_t pk_bytes(int ld, int N) { return pk_align(pk_off_alpha(ld, N) + sizeof(float) * (size_t)ld); }
 size_t packed_model_bytes(int ld, int N) { return pk_bytes(ld, N); }
 
 // grid = models, block = 256: model -> record (PACK) or record -> model (the descriptor must already point at allocated
-// storage of the right size)
+// storage of the right size and kind).  Bit 30 of a slot entry = factor record (kind 1): tiles <-> Lt, alpha <-> alpha.
+constexpr int kPackFactorBit = 1 << 30;
 template <bool PACK>
 __global__ __launch_bounds__(256) void model_pack_kernel(const ClusterModel* __restrict__ models, const int* __restrict__ slots,
                                                          char* __restrict__ buf, const unsigned long long* __restrict__ offs) {
-    const ClusterModel m = models[slots[blockIdx.x]];
+    const int entry = slots[blockIdx.x];
+    const bool factor = (entry & kPackFactorBit) != 0;
+    const ClusterModel m = models[entry & ~kPackFactorBit];
     char* rec = buf + offs[blockIdx.x];
     const int tid = threadIdx.x;
     if (PACK && tid == 0) {
         int* h = reinterpret_cast<int*>(rec);
         h[0] = m.dim; h[1] = m.N; h[2] = m.ng; h[3] = m.K; h[4] = m.ld; h[5] = m.nb;
         reinterpret_cast<float*>(rec)[6] = m.scale;
-        for (int i = 7; i < 16; ++i) h[i] = 0;
+        h[7] = factor ? 1 : 0;
+        for (int i = 8; i < 16; ++i) h[i] = 0;
     }
     const int ld = m.ld, N = m.N;
     int* ri = reinterpret_cast<int*>(rec + pk_off_ri());
     float4* x4 = reinterpret_cast<float4*>(rec + pk_off_x4(ld));
     float4* xt = reinterpret_cast<float4*>(rec + pk_off_xt(ld, N));
+    float* al = reinterpret_cast<float*>(rec + pk_off_alpha(ld, N));
     const size_t nxt = (size_t)256 * (ld / 32) * (ld / 32 + 1) / 2;   // float4s
+    float* tiles = factor ? m.Lt : m.Xt;
     if (PACK) {
         for (int i = tid; i < ld; i += 256) ri[i] = m.rowinfo[i];
         for (int i = tid; i < N; i += 256) x4[i] = reinterpret_cast<const float4*>(m.x4)[i];
-        for (size_t i = tid; i < nxt; i += 256) xt[i] = reinterpret_cast<const float4*>(m.Xt)[i];
+        for (size_t i = tid; i < nxt; i += 256) xt[i] = reinterpret_cast<const float4*>(tiles)[i];
+        for (int i = tid; i < ld; i += 256) al[i] = factor ? m.alpha[i] : 0.f;
     } else {
         for (int i = tid; i < ld; i += 256) m.rowinfo[i] = ri[i];
         for (int i = tid; i < N; i += 256) reinterpret_cast<float4*>(m.x4)[i] = x4[i];
-        for (size_t i = tid; i < nxt; i += 256) reinterpret_cast<float4*>(m.Xt)[i] = xt[i];
+        for (size_t i = tid; i < nxt; i += 256) reinterpret_cast<float4*>(tiles)[i] = xt[i];
+        if (factor) for (int i = tid; i < ld; i += 256) m.alpha[i] = al[i];
     }
 }
 

@@ -82,7 +82,10 @@ public:
     size_t packed_bytes(const int* slots, int n) const;                 // largest record among the listed models
     // record i at byte offset offs[i] of d_buf (offs == nullptr: i * stride; otherwise stride is ignored and the records
     // sit back to back at their own sizes: offs has n + 1 entries, the last one the end of the buffer)
-    int pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs = nullptr);
+    // factors = true: a model whose explicit inverse is still pending (lazy inverse) travels as its FACTOR (Lt + alpha, a kind-1
+    // record of the same size) instead of forcing the inverse here; models that have their X travel as before.
+    int pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs = nullptr, bool factors = false);
+    int last_unpack_factors = 0;    // factor records among the models of the last unpack_models() (their inverse is deferred)
     // records -> models.  slots_inout[i] < 0: a new slot is created and returned there; else that slot is (re)used.
     // The models are predict-only (no factor, no training scratch).
     int unpack_models(const void* d_buf, int n, size_t stride, int* slots_inout, hipStream_t s, const size_t* offs = nullptr);
@@ -140,7 +143,7 @@ public:
     bool train_pending() const { return pend_active_; }
 
 private:
-    enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2 };
+    enum AllocKind { kAllocFull = 0, kAllocPredictOnly = 1, kAllocLeanFactor = 2, kAllocFactorImport = 3 };
     int alloc_model(int slot, int N, int ng, int kind = kAllocFull);
     int train_batch_impl(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s);
     void build_inverse_work(const std::vector<int>& tab, int jbeg, int jend, int kLongCol, std::vector<int>& work,

@@ -155,7 +155,7 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
     int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     const size_t szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
     free_model_mem(m);
-    if (kind != kAllocFull) {
+    if (kind == kAllocPredictOnly || kind == kAllocLeanFactor) {
         // what K4 reads (rowinfo, x4, Xt): imported models and models trained by the fused on-chip kernel;
         // kAllocLeanFactor adds the factor, alpha and the gradient index for parity tests / gpis_ongpis_get_model
         size_t oR = 0, szR = sizeof(int) * ld;
@@ -174,6 +174,29 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
         m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
         if (kind == kAllocLeanFactor) { m.L = (float*)(base + oL); m.alpha = (float*)(base + oA); m.gidx = (int*)(base + oG); }
         m.base = base;
+        dirty_ = true;
+        return GPIS_OK;
+    }
+    if (kind == kAllocFactorImport) {
+        // a factor received from another rank: the prediction side plus what K3b needs to produce it -- the re-tiled factor, the
+        // transposed-tile scratch and alpha (6 K^2 bytes until the inverse exists, 2 K^2 after the trim)
+        size_t oR = 0, szR = sizeof(int) * ld;
+        size_t oX = align_up(oR + szR, 256), szX = sizeof(float) * 4 * (size_t)N;
+        size_t oXt = align_up(oX + szX, 256);
+        const size_t total_p = align_up(oXt + szT, 256);
+        size_t oA = 0, szA = sizeof(float) * ld;
+        size_t oT = align_up(oA + szA, 256);
+        size_t oZt = align_up(oT + szT, 256);
+        const size_t total_s = align_up(oZt + szT, 256);
+        char* base = (char*)pool_alloc(pool_, total_p);
+        if (!base) return GPIS_ERR_HIP;
+        char* sc = (char*)pool_alloc(pool_, total_s);
+        if (!sc) { pool_free(pool_, base); return GPIS_ERR_HIP; }
+        std::memset(&m, 0, sizeof(ClusterModel));
+        m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
+        m.rowinfo = (int*)(base + oR); m.x4 = (float*)(base + oX); m.Xt = (float*)(base + oXt);
+        m.alpha = (float*)(sc + oA); m.Lt = (float*)(sc + oT); m.Zt = (float*)(sc + oZt);
+        m.base = base; m.scratch = sc;
         dirty_ = true;
         return GPIS_OK;
     }
@@ -780,9 +803,16 @@ size_t OnGPISStore::packed_bytes(const int* slots, int n) const {
 // unpack, the gathered headers (16 n ints), in d_slots_.
 static size_t pk_scratch_ints(int n) { return (size_t)n + 2 * (size_t)n + 16 * (size_t)n + 8; }
 
-int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs) {
+int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride, hipStream_t s, const size_t* offs, bool factors) {
     if (n <= 0) return GPIS_OK;
-    { const int erc = ensure_inverses(s); if (erc) return erc; }
+    if (factors) { const int frc = train_finish(); if (frc) return frc; }
+    else { const int erc = ensure_inverses(s); if (erc) return erc; }
+    // (factors: a model whose X is pending and whose factor is still here travels as kind 1; everything else has its X)
+    auto as_factor = [&](int slot) {
+        if (!factors || slot < 0 || slot >= (int)xstale_.size() || !xstale_[slot]) return false;
+        const ClusterModel* m = model(slot);
+        return m && m->scratch && m->Lt && m->alpha;
+    };
     if (!offs && stride % 256 != 0) return GPIS_ERR_ARG;
     auto rec_off = [&](int i) { return offs ? offs[i] : (size_t)i * stride; };
     auto rec_room = [&](int i) { return offs ? offs[i + 1] - offs[i] : stride; };
@@ -793,7 +823,7 @@ int OnGPISStore::pack_models(const int* slots, int n, void* d_buf, size_t stride
         const ClusterModel* m = model(slots[i]);
         if (m && m->base && m->Xt) {
             if (packed_model_bytes(m->ld, m->N) > rec_room(i)) return GPIS_ERR_ARG;
-            present.push_back(slots[i]); poff.push_back((unsigned long long)rec_off(i));
+            present.push_back(as_factor(slots[i]) ? (slots[i] | (1 << 30)) : slots[i]); poff.push_back((unsigned long long)rec_off(i));
         } else if (rec_room(i) < 64) return GPIS_ERR_ARG;
     }
     int rc = sync_models(s);
@@ -849,10 +879,12 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
     auto bail = [&](int rc) { for (int sl : created) release_slot(sl); return rc; };
     std::vector<int> present;
     std::vector<unsigned long long> poff;
+    last_unpack_factors = 0;
     for (int i = 0; i < n; ++i) {
         const int* h = &hdr[(size_t)16 * i];
-        const int dim = h[0], N = h[1], ng = h[2], K = h[3], ld = h[4];
+        const int dim = h[0], N = h[1], ng = h[2], K = h[3], ld = h[4], kind = h[7];
         const bool absent = (K == 0 && N == 0);
+        if (!absent && kind != 0 && kind != 1) return bail(GPIS_ERR_ARG);
         if (!absent && (dim != dim_ || N <= 0 || ng < 0 || ng > N || K != N + dim * ng || ld != (int)align_up((size_t)K + 1, 32) ||
                         packed_model_bytes(ld, N) > rec_room(i)))
             return bail(GPIS_ERR_ARG);
@@ -865,10 +897,11 @@ int OnGPISStore::unpack_models(const void* d_buf, int n, size_t stride, int* slo
             dirty_ = true;
             continue;
         }
-        if (slots[i] < (int)xstale_.size()) xstale_[slots[i]] = 0;     // (an imported model carries its X)
-        int rc = alloc_model(slots[i], N, ng, kAllocPredictOnly);
+        if (slots[i] < (int)xstale_.size()) xstale_[slots[i]] = 0;     // (a prediction record carries its X)
+        int rc = alloc_model(slots[i], N, ng, kind == 1 ? kAllocFactorImport : kAllocPredictOnly);
         if (rc) return bail(rc);
-        present.push_back(slots[i]); poff.push_back(aoff[i]);
+        if (kind == 1) { mark_stale(slots[i]); ++last_unpack_factors; }   // its X is computed by the first prediction (ensure_inverses)
+        present.push_back(kind == 1 ? (slots[i] | (1 << 30)) : slots[i]); poff.push_back(aoff[i]);
     }
     int rc = sync_models(s);
     if (rc) return bail(rc);

@@ -83,6 +83,12 @@ int   gpis3_device(void* map);                                 /* device the map
  *   gpis3_shard_finish(map)                             builds the cluster table: test() is valid again
  * With world = 1 (default) update() is complete on return and none of the calls is needed. */
 int   gpis3_set_shard(void* map, int rank, int world);
+/* What the records of a sharded update carry (same size either way): mode 1 = FACTOR records for models whose explicit inverse is
+ * still pending (lazy inverse: -L re-tiled + alpha; the receiver computes X = L^-1 when it first predicts with the model, so no
+ * rank inverts a cluster that is retrained before anybody asks), mode 0 = prediction records (X; packing forces the inverse on
+ * the owner), mode -1 (default) = 1 with the lazy inverse, 0 with the eager one.  Also applies to maps over several devices.
+ * gpis3_stats out[27] = factor records received in the last exchange. */
+int   gpis3_set_shard_factors(void* map, int mode);
 int   gpis3_shard_info(void* map, int* out, int n);
 long long gpis3_shard_bytes(void* map, int owner);
 int   gpis3_shard_pack(void* map, void* d_buf, void* hip_stream);
@@ -91,13 +97,13 @@ int   gpis3_shard_finish(void* map);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */
-/* out[0..26]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
+/* out[0..27]: obsgp groups trained, obsgp queries, clusters trained (cumulative), late re-evaluations, clusters in table,
  * GP evaluations of last test, ms in K4 of last test (profiling on), device bytes, algorithmic flops of last test, K4 launches,
  * ms in K6+K3+K3b of last update (profiling on), model bytes, update phases ms [preproc, ObsGP train, re-evaluation,
  * new points, updateGPs], algorithmic flops / bytes / clusters / largest K of the last training batch, ms and clusters of the
  * last deferred inverse pass (profiling on), bytes received in the last in-library model exchange, pipelined update on (0/1),
  * CUs the training streams leave free, host replays of the last update() over all devices of the map (1: the host logic ran
- * once, on the lead device, however many devices train) */
+ * once, on the lead device, however many devices train), factor records received in the last model exchange (inverses deferred) */
 int   gpis3_stats(void* map, double* out, int n);
 /* Map checkpoint (optional; the reference keeps its map only in the mex singleton): gpis3_save writes the spatial
  * index, the surface points with their data and every trained model as its packed prediction record (about 2 K^2 bytes per

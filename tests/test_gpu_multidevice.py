@@ -86,3 +86,26 @@ def test_gateway_uses_every_listed_device(monkeypatch):
         assert float(np.mean(np.all(res[0].T == ro, axis=1))) >= 0.9995
         assert np.array_equal(g.call(1, "getAllPoints")[0].T, om.nodes()[:, :3])
     g.call(0, "reset")
+
+
+def test_factor_records_keep_the_lazy_inverse_across_the_exchange():
+    """with the lazy inverse the exchange ships FACTORS (model_pack.hip kind 1, the same bytes) and every
+    receiver inverts when it first predicts -- several updates without a test() in between never invert on any rank; forcing
+    prediction records gives the same bits."""
+    import gpismap_amd
+    grid = replay.synthetic_grid(24)
+    one = gpismap_amd.GPisMap3()
+    fac = gpismap_amd.GPisMap3(devices=[0, 0])                       # default: factor records (lazy inverse)
+    xrec = gpismap_amd.GPisMap3(devices=[0, 0]); xrec.set_shard_factors(0)
+    for f in range(3):
+        d = replay.synthetic_depth(f)
+        for m in (one, fac, xrec):
+            m.update(d, replay.IDENTITY_POSE)
+        sf, sx = fac.stats(), xrec.stats()
+        assert sf["exchange_bytes"] == sx["exchange_bytes"] == fac.shard_bytes(1)     # same record sizes either way
+        assert sf["deferred_inverses"] > 0 and sx["deferred_inverses"] == 0
+        assert sf["last_inverse_jobs"] == 0 or f == 0                  # no inverse pass ran inside the sharded update()
+    a, b, c = one.test(grid), fac.test(grid), xrec.test(grid)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.array_equal(a.view(np.uint32), c.view(np.uint32))
+    assert np.array_equal(one.nodes(), fac.nodes())
