@@ -74,6 +74,9 @@ typedef const int __attribute__((address_space(1))) * giptr;
                             // waves generating (6 x 4 rows per group) 1497 ms/step, unified 1360 ms/step
 #endif
 
+#ifndef K4_XCD_REMAP
+#define K4_XCD_REMAP 1      // eight consecutive tiles of the list on one XCD (0: tile = workgroup id)
+#endif
 #ifndef K4_BT
 #define K4_BT 1             // B tiles in LDS k-contiguous per column: Bt[n][h][kk] = B[2 kk + h][n], so that the 16 operand values of a lane are
                             // FOUR 16-byte reads instead of sixteen 4-byte reads (the operand reads of 16 wavefronts took half of the LDS cycles)
@@ -88,7 +91,18 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     constexpr int WC = W - WP;    // wavefronts that own block rows (consumers)
     constexpr int RG = NBW * WC;  // block rows per row group
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tile = blockIdx.x;
+    // Workgroup ids go round the eight XCDs (id b runs on XCD b % 8), and the tiles of ONE cluster are consecutive in the tile list:
+    // taken as they come, eight consecutive 8-query tiles land on eight different L2s and every one of them fetches the cluster's X
+    // from HBM for itself -- the stress configuration (64 queries = 8 tiles per cluster) read every model eight times.  Inside
+    // every block of 64 workgroup ids the (id / 8, id % 8) grid is transposed: XCD x takes the tiles 8x .. 8x + 7 of the block, so
+    // eight consecutive tiles share one L2 and run at about the same time; every XCD still takes every eighth group of eight
+    // (cutting the LIST into eight contiguous ranges instead was measured: stress +6 %, but the 256^3 bench 0.75 -> 0.63 of peak,
+    // the ranges of a launch differ by the K^2 of their clusters).  Which workgroup evaluates a tile does not enter any result.
+    int tile = blockIdx.x;
+    if (K4_XCD_REMAP) {
+        const int n64 = (int)gridDim.x & ~63;
+        if (tile < n64) tile = (tile & ~63) | ((tile & 7) << 3) | ((tile >> 3) & 7);
+    }
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the row ownership logic in SGPRs
     const int h = lane >> 5, l31 = lane & 31;
