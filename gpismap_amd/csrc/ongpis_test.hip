@@ -77,9 +77,6 @@ typedef const int __attribute__((address_space(1))) * giptr;
 #ifndef K4_XCD_REMAP
 #define K4_XCD_REMAP 1      // eight consecutive tiles of the list on one XCD (0: tile = workgroup id)
 #endif
-#ifndef K4_TAB_UNROLL
-#define K4_TAB_UNROLL 1
-#endif
 #ifndef K4_BT
 #define K4_BT 1             // B tiles in LDS k-contiguous per column: Bt[n][h][kk] = B[2 kk + h][n], so that the 16 operand values of a lane are
                             // FOUR 16-byte reads instead of sixteen 4-byte reads (the operand reads of 16 wavefronts took half of the LDS cycles)
@@ -149,30 +146,17 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
 
     // ---- stage 1: exp table, one entry per (training point, query slot) ----
     if (TABLE) {
-        // K4_TAB_UNROLL entries per trip: the exponentials are ~60 dependent double-precision instructions each -- several in one
-        // basic block let the scheduler interleave them (one at a time, the pass is latency-bound: profiles/r05_k4_stamps.txt)
-        constexpr int TU = K4_TAB_UNROLL;
-        const int total = N * 8 * QS;
-        for (int idx0 = tid; idx0 < total; idx0 += TU * 64 * W) {
-            float arg[TU];
-            int dst[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) {
-                const int idx = idx0 + u * 64 * W;
-                const int p = min(idx, total - 1) / (8 * QS), s = idx % (8 * QS);
+        for (int idx = tid; idx < N * 8 * QS; idx += 64 * W) {
+            const int p = idx / (8 * QS), s = idx % (8 * QS);
+            double e = 0.0;
+            if (s < jcnt) {
                 const float4 xp = x4[p];
                 const float4 q = s_xq[s];
                 const float d0 = xp.x - q.x, d1 = xp.y - q.y, d2 = xp.z - q.z;
                 const float r = (dim == 3) ? sqrtf((d0 * d0 + d1 * d1) + d2 * d2) : sqrtf(d0 * d0 + d1 * d1);
-                arg[u] = -a * r;
-                dst[u] = (idx < total) ? p * ES + s : -1;
-                if (s >= jcnt) arg[u] = -INFINITY;          // unused query slot: exp(-inf) = 0, as before
+                e = exp((double)(-a * r));
             }
-            double e[TU];
-#pragma unroll
-            for (int u = 0; u < TU; ++u) e[u] = exp((double)arg[u]);
-#pragma unroll
-            for (int u = 0; u < TU; ++u) if (dst[u] >= 0) etab[dst[u]] = e[u];
+            etab[p * ES + s] = e;
         }
         __syncthreads();
     }
