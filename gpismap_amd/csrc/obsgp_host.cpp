@@ -35,7 +35,8 @@ struct DevPool {
 };
 // Standard-size chunks of destroyed pools are kept per device for the next pool of the process (a 512 MiB hipMalloc
 // costs milliseconds -- a map that is reset / re-created per sequence paid for its whole pool again, in the middle of its
-// first frames); bounded by GPIS_POOL_CACHE_GB (default 4, 0 = give everything back at once).  gpis_pool_cache_trim() (C-ABI,
+// first frames); bounded by GPIS_POOL_CACHE_GB (default 16, 0 = give everything back at once; a 4 GB default was measured in round 5: the
+// F = 5 bench map holds 7 GB of models, and every fusion after the first paid 3 x 5 ms of hipMalloc in its last frame again).  gpis_pool_cache_trim() (C-ABI,
 // also run at process exit by the Python mirror) hands the cached chunks back to the driver; a hipMalloc of the library that
 // fails retries once after trimming the cache, so cached chunks never make an allocation of this library fail.
 namespace {
@@ -43,7 +44,7 @@ constexpr size_t kPoolChunk = (size_t)512 << 20;
 std::mutex g_chunk_mu;
 std::map<int, std::vector<void*>> g_chunk_cache;     // device -> free standard-size chunks
 size_t chunk_cache_limit() {
-    static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 4.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
+    static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 16.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
     return lim;
 }
 void* chunk_cache_take() {

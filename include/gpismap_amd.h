@@ -33,7 +33,7 @@ typedef struct gpis_cam {  /* reference camParam, GPisMap3.h:29-46 */
 /* number of HIP devices visible (0 when no GPU: every compute entry then fails loudly) */
 int gpis_device_count(void);
 /* The library keeps the standard-size chunks of destroyed device pools per device for the next map of the process (bounded by
- * GPIS_POOL_CACHE_GB, default 4).  gpis_pool_cache_trim() hands them back to the driver -- call it when another library in the
+ * GPIS_POOL_CACHE_GB, default 16).  gpis_pool_cache_trim() hands them back to the driver -- call it when another library in the
  * process needs the memory; returns the bytes released.  No map may be in use on another thread during the call. */
 unsigned long long gpis_pool_cache_trim(void);
 const char* gpis_version(void);

@@ -199,6 +199,25 @@ def test_flat_tree_matches_oracle_tree(tmp_path):
     assert r.stdout.count("identical") == 12 and "MISMATCH" not in r.stdout
 
 
+def test_flat_tree_under_address_and_ub_sanitizers(tmp_path):
+    """The host spatial index and the oracle's tree under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build only: GPU ASan is
+    not available on the pool): the same random insert / remove / range-query / frozen-witness sequences as above, any
+    out-of-bounds index, use-after-free of a recycled node or signed overflow aborts the run."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "tree_check_san")
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I" + os.path.join(root, "gpismap_amd", "csrc"), "-I" + os.path.join(root, "oracle"),
+                        os.path.join(root, "tests", "cpp", "tree_check.cpp"), "-o", exe], capture_output=True, text=True)
+    if r.returncode != 0 and ("asan" in r.stderr.lower() or "sanitize" in r.stderr.lower()):
+        pytest.skip("sanitizer runtime not available to g++ here: " + r.stderr.strip().splitlines()[-1])
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    r = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert r.stdout.count("identical") == 12 and "MISMATCH" not in r.stdout
+
+
 def test_no_kernel_spills_or_uses_scratch():
     """the gfx950 code objects of the built library, read through llvm-readelf --notes
     (tools/kernel_resources.py): no kernel may spill a vector register or carry a private (scratch) segment -- round 2's
