@@ -337,7 +337,7 @@ int OnGPISStore::train_batch_impl(const std::vector<TrainJob>& jobs, const std::
         const TrainJob& tj = jobs[j];
         int K = tj.n + dim_ * tj.ng;
         if (K > ONGPIS_MAX_K || !ongpis_eval_fits(tj.n, (int)align_up((size_t)K + 1, 32))) {
-            fprintf(stderr, "[gpismap_amd] cluster with N=%d, K=%d exceeds what the prediction kernel can stage in LDS (4 ld + 16 N bytes + two B blocks <= 158 KB; K <= %d): previous model kept\n", tj.n, K, ONGPIS_MAX_K);
+            fprintf(stderr, "[gpismap_amd] cluster with N=%d, K=%d exceeds what the prediction kernel can stage in LDS (4 ld + 16 N bytes + three B blocks <= 158 KB; K <= %d): previous model kept\n", tj.n, K, ONGPIS_MAX_K);
             if (!deferred_rc) deferred_rc = GPIS_ERR_LIMIT;
             continue;
         }

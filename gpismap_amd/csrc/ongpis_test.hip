@@ -15,9 +15,12 @@
 // (accumulators in registers), streams the X tiles of those rows from L2/HBM exactly once and reads the
 // B tiles all wavefronts share from LDS.  alpha rides along as row K of X, so row K of V is the mean
 // k*^T alpha (one ascending fmaf chain) and needs no separate reduction.
-//   * B is generated in chunks of CB column blocks into a double-buffered LDS ring: half of the
-//     wavefronts generate chunk i+1 before multiplying chunk i, the other half after -- on every SIMD one
-//     wavefront feeds the vector ALU while the other feeds the matrix pipe.  One barrier per chunk.
+//   * B is generated in chunks of CB column blocks into a THREE-slot LDS ring handed over through LDS counters (round 5): a
+//     wavefront multiplies chunk i as soon as its tiles are counted in, then generates its tile of chunk i+2 (the duty goes
+//     round the wavefronts) once every wavefront is through with the chunk that slot held before.  No workgroup barrier in
+//     the loop: a wavefront may run a chunk ahead of the slowest one, which absorbs the per-chunk imbalance of the
+//     triangular product -- with a barrier per chunk (rounds 2-4: two slots, half of the wavefronts generating before
+//     multiplying, half after) 15 % of the wave-cycles waited there.  -DK4_RING=0 builds the barrier variant.
 //   * block rows are dealt to the wavefronts from the largest down, snake-wise (row b costs b+1 tile
 //     products); clusters with more than 4 W block rows run several row groups (B chunks are regenerated
 //     for the later, cheaper groups), so there is no upper limit on K.
@@ -74,6 +77,14 @@ typedef const int __attribute__((address_space(1))) * giptr;
                             // waves generating (6 x 4 rows per group) 1497 ms/step, unified 1360 ms/step
 #endif
 
+#ifndef K4_RING
+#define K4_RING 1           // 1: the B chunks in a THREE-slot ring handed over through LDS counters instead of a workgroup barrier per chunk --
+                            // a wavefront may run one chunk ahead of the slowest one, so the per-chunk imbalance of the triangular product
+                            // (profiles/r05_k4_stamps.txt: 15 % of the wave-cycles wait at that barrier) is absorbed instead of waited for
+#endif
+#ifndef K4_RING_SLOTS
+#define K4_RING_SLOTS 3
+#endif
 #ifndef K4_XCD_REMAP
 #define K4_XCD_REMAP 1      // eight consecutive tiles of the list on one XCD (0: tile = workgroup id)
 #endif
@@ -83,6 +94,24 @@ typedef const int __attribute__((address_space(1))) * giptr;
 #endif
 constexpr int kTileStride = 36;                 // floats per row (K4_BT: per column) of a B tile in LDS: conflict-free writes AND operand reads
 constexpr int kTileFloats = 32 * kTileStride;   // 1152
+
+// K4_RING hand-overs through LDS counters (cumulative, never reset).  The counter is read through readfirstlane: a per-lane loop
+// condition would make everything after the loop divergent to the compiler (waterfall loops around the buffer loads, wave-uniform
+// values demoted to VGPRs).  The wait is bounded: a protocol error must not hang the queue (the results are then wrong and the
+// parity tests say so).
+typedef volatile int __attribute__((address_space(3))) * lds_cnt_t;
+__device__ __forceinline__ void k4_ring_wait(lds_cnt_t p, int need) {
+    for (int spins = 0; spins < (1 << 22); ++spins) {
+        if (__builtin_amdgcn_readfirstlane(*p) >= need) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+__device__ __forceinline__ void k4_ring_signal(lds_cnt_t p, int lane) {
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // this wavefront's LDS traffic on the slot is complete
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_fetch_add((int __attribute__((address_space(3)))*)p, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // W wavefronts of which WP only generate B tiles (0: every wavefront generates and multiplies), NBW block rows per
 // multiplying wavefront and row group, QS query sets of 8 per workgroup (every X tile feeds QS tile products)
@@ -121,6 +150,8 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     float* red = reinterpret_cast<float*>(smem);                       // [W][NC] sums of squares, then [NC] means
     float4* s_xq = reinterpret_cast<float4*>(red + W * NC + NC);       // [16] the tile's query points
     int* s_ri = reinterpret_cast<int*>(s_xq + 16) + 32;                // [ld] row -> point | component
+    lds_cnt_t ring_cnt = (lds_cnt_t)(reinterpret_cast<int*>(s_xq + 16));    // K4_RING: [0..3] tiles generated per slot, [8..11] wavefronts done per slot (cumulative)
+    if (K4_RING && tid < 16) ring_cnt[tid] = 0;
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
     double* etab = reinterpret_cast<double*>(s_x4 + N);                // [N][16] exp table (optional)
     float* Bbuf = reinterpret_cast<float*>(etab + (TABLE ? (((size_t)N * ES + 1) & ~(size_t)1) : 0));   // [NSLOT][CB][QS][32*36]
@@ -227,7 +258,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     };
 
     // ---- B chunks.  The chunks of all row groups form one sequence gci = 0, 1, ...; chunk gci lives in ring slot
-    // gci % NSLOT (NSLOT = 2: the chunk being multiplied and the one being generated); one workgroup barrier per chunk.
+    // gci % NSLOT (ring mode: three slots and LDS counters; barrier mode: two slots, one workgroup barrier per chunk).
     // WP = 0: tile j of a chunk is made by wave j % W, every wave generates AND multiplies.  WP > 0 (the widest classes):
     // the last WP waves only generate, the first WC only multiply -- the accumulators (64 VGPRs) and the generation code
     // (double-precision kernel entries) are then never live in the same wave, which is what keeps the kernel inside
@@ -236,14 +267,34 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     const int ngroups = (nbx + RG - 1) / RG;
     auto group_cmax = [&](int g) { return min(nbx - 1 - g * RG, nb - 1); };   // last column block a row of group g multiplies with
     int pg = 0, pci = 0, pgci = 0;   // producer cursor: group, chunk in group, chunk in sequence
+    // K4_RING: expected cumulative tile count per slot (what the slot's counter shows once every chunk produced into it so far is
+    // complete); a wait is bounded (a protocol error would otherwise hang the queue: the results are then wrong and the parity
+    // tests say so)
+    int exp_gen0 = 0, exp_gen1 = 0, exp_gen2 = 0, exp_gen3 = 0;      // (up to four slots: K4_RING_SLOTS)
     auto produce_next = [&]() {
         if (pg >= ngroups) return;
         const int cmax = group_cmax(pg);
-        float* slot = Bbuf + (size_t)(pgci % NSLOT) * CB * QS * kTileFloats;
+        const int pslot = pgci % NSLOT;
+        float* slot = Bbuf + (size_t)pslot * CB * QS * kTileFloats;
         const int c0 = pci * CB;
-        const int j0 = (WP > 0) ? wave - WC : wave, jstep = (WP > 0) ? WP : W;
-        for (int j = j0; j < CB && c0 + j <= cmax; j += jstep)
-            for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + j, qs, slot + (size_t)(j * QS + qs) * kTileFloats);
+        if (K4_RING) {
+            // tile t of chunk p is made by wavefront (t + p CB) mod W: the duty goes round, every wavefront generates the same
+            // number of tiles over a few chunks.  The slot is free once every wavefront has multiplied the chunk it held before.
+            const int nt = min(CB, cmax - c0 + 1);
+            const int my_t = (((wave - pgci * CB) % W) + W) % W;
+            if (my_t < nt) {
+                k4_ring_wait(ring_cnt + 8 + pslot, W * (pgci / NSLOT));
+                for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + my_t, qs, slot + (size_t)(my_t * QS + qs) * kTileFloats);
+                k4_ring_signal(ring_cnt + pslot, lane);
+            }
+            // (unconditional adds: an if / else chain over the three becomes a SELECT OF POINTERS to captured variables, and with it every
+            // capture of the kernel's lambdas stays in scratch memory -- 240 allocas survived)
+            exp_gen0 += (pslot == 0) ? nt : 0; exp_gen1 += (pslot == 1) ? nt : 0; exp_gen2 += (pslot == 2) ? nt : 0; exp_gen3 += (pslot == 3) ? nt : 0;
+        } else {
+            const int j0 = (WP > 0) ? wave - WC : wave, jstep = (WP > 0) ? WP : W;
+            for (int j = j0; j < CB && c0 + j <= cmax; j += jstep)
+                for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + j, qs, slot + (size_t)(j * QS + qs) * kTileFloats);
+        }
         ++pgci;
         if (++pci > cmax / CB) { pci = 0; ++pg; }
     };
@@ -302,9 +353,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
         }
     } else {
         // ---- multiplying wavefronts (and, with WP = 0, generating ones)
-        const bool gen_first = (W < 2) || (wave < W / 2);   // WP = 0: half of the waves generate before multiplying, half after
+        // barrier mode: half of the waves generate before multiplying, half after; ring mode: every wave multiplies first (a wave that
+        // generates first waits for the slowest wave of the chunk before: measured 0.4 % slower)
+        const bool gen_first = !K4_RING && ((W < 2) || (wave < W / 2));
         if (WP == 0) for (int i = 0; i < LA; ++i) produce_next();
-        __syncthreads();
+        if (!K4_RING) __syncthreads();
         K4_STAMP();
         int gci = 0;
         for (int g = 0; g < ngroups; ++g) {
@@ -333,6 +386,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             for (int ci = 0; ci < nch; ++ci, ++gci) {
                 if (WP == 0 && gen_first) produce_next();
                 K4_LAP(0);
+                if (K4_RING) {      // chunk gci complete in its slot?  (its tiles were generated one or two chunks ago)
+                    const int sl = gci % NSLOT;
+                    k4_ring_wait(ring_cnt + sl, sl == 0 ? exp_gen0 : (sl == 1 ? exp_gen1 : (sl == 2 ? exp_gen2 : exp_gen3)));
+                    K4_LAP(2);
+                }
                 {
                     if (K4_PRIO) __builtin_amdgcn_s_setprio(K4_PRIO);
                     const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * QS * kTileFloats;
@@ -399,9 +457,10 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                 }
                 if (K4_PRIO) __builtin_amdgcn_s_setprio(0);
                 K4_LAP(1);
+                if (K4_RING) k4_ring_signal(ring_cnt + 8 + gci % NSLOT, lane);       // this wavefront is through with chunk gci
                 if (WP == 0 && !gen_first) produce_next();
                 K4_LAP(0);
-                __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
+                if (!K4_RING) __syncthreads();   // chunk gci multiplied by every wave, chunk gci + LA generated
                 K4_LAP(2);
                 K4_LAP_COUNT(4);
             }
@@ -486,22 +545,28 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     const size_t share = std::min(hard, hard * W / kWavesPerCU);
     const size_t blk = kQS * sizeof(float) * kTileFloats;    // one column block, all query sets
     int use_table = args_in.use_table ? 1 : 0;
-#ifdef K4_NO_TABLE
+#if K4_RING || defined(K4_NO_TABLE)
+    // Ring mode: never an exp table.  The table of a K ~ 1000 cluster takes 22 KB of the workgroup's 79 KB, and what the ring wants is
+    // WIDE chunks: three slots of five column blocks without the table 0.772-0.775 of peak, three slots of three with it 0.751,
+    // two slots of five with it and a barrier per chunk (rounds 2-4) 0.748-0.753.  Every entry evaluates its own exponential, the
+    // path the largest clusters always took (test_predict_without_exp_table_is_identical).
     use_table = 0;
+#endif
+#if K4_RING
+    const int nslot = K4_RING_SLOTS;
+#elif defined(K4_NSLOT)
+    const int nslot = K4_NSLOT;
+#else
+    const int nslot = 2;   // (barrier mode) two large chunks beat three smaller ones: 811 vs 851 ms on the 256^3 bench
 #endif
     size_t fixed = eval_lds_fixed(W, maxN, maxLd, use_table);
     if (use_table && fixed + 4 * blk > share) {              // the exp table does not fit beside a useful ring
         const size_t f0 = eval_lds_fixed(W, maxN, maxLd, 0);
         if (f0 + 4 * blk <= share || fixed + 2 * blk > hard) { use_table = 0; fixed = f0; }
     }
-    if (fixed + 2 * blk > hard) return GPIS_ERR_LIMIT;
-    const size_t budget = std::min(hard, std::max(share, fixed + 2 * blk));
+    if (fixed + nslot * blk > hard) return GPIS_ERR_LIMIT;
+    const size_t budget = std::min(hard, std::max(share, fixed + nslot * blk));
     const int nblk = (int)((budget - fixed) / blk);           // column blocks the ring can hold
-#ifdef K4_NSLOT
-    int nslot = K4_NSLOT;
-#else
-    int nslot = 2;   // two large chunks beat three smaller ones (fewer synchronisation points): 811 vs 851 ms on the 256^3 bench
-#endif
     int cb = std::max(1, std::min(nblk / nslot, 8));
     cb = std::min(cb, std::max(1, maxLd / 32));
     args.use_table = use_table;
@@ -512,8 +577,12 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     static const kern_t kern[2][4] = {
         {ongpis_eval_kernel<1, false, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, false, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, false, kQS, K4_NBW, 0>,
          ongpis_eval_kernel<K4_W3, false, kQS, K4_NBW, K4_WP3>},
+#if K4_RING || defined(K4_NO_TABLE)      // (the table kernels are not part of such a build)
+        {nullptr, nullptr, nullptr, nullptr}};
+#else
         {ongpis_eval_kernel<1, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<2, true, kQS, K4_NBW, 0>, ongpis_eval_kernel<4, true, kQS, K4_NBW, 0>,
          ongpis_eval_kernel<K4_W3, true, kQS, K4_NBW, K4_WP3>}};
+#endif
     const int kidx = wclass < 3 ? wclass : (wclass == 3 ? 2 : 3);
 #ifdef GPIS_EXPERIMENTS
     // several consecutive tiles per workgroup, software-pipelined across the tiles (K4_SEG tiles; 0: one tile per workgroup, the kernel above)
@@ -558,7 +627,7 @@ int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }
 bool ongpis_eval_fits(int N, int ld) {
     const int W = kClassW[ongpis_class_of_nbx(ld / 32)];
     const size_t blk = kQS * sizeof(float) * kTileFloats;
-    return eval_lds_fixed(W, N, ld, 0) + 2 * blk <= (size_t)158 * 1024;
+    return eval_lds_fixed(W, N, ld, 0) + (K4_RING ? K4_RING_SLOTS : 2) * blk <= (size_t)158 * 1024;
 }
 
 }  // namespace gpis
