@@ -100,11 +100,13 @@ constexpr int kTileFloats = 32 * kTileStride;   // 1152
 // values demoted to VGPRs).  The wait is bounded: a protocol error must not hang the queue (the results are then wrong and the
 // parity tests say so).
 typedef volatile int __attribute__((address_space(3))) * lds_cnt_t;
-__device__ __forceinline__ void k4_ring_wait(lds_cnt_t p, int need) {
-    for (int spins = 0; spins < (1 << 22); ++spins) {
+__device__ __forceinline__ void k4_ring_wait(lds_cnt_t p, int need, lds_cnt_t expired) {
+    int spins = 0;
+    for (; spins < (1 << 22); ++spins) {
         if (__builtin_amdgcn_readfirstlane(*p) >= need) break;
         __builtin_amdgcn_s_sleep(1);
     }
+    if (spins == (1 << 22)) *expired = 1;      // (a protocol error: the tile's results are written as NaN, never as plausible numbers)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 __device__ __forceinline__ void k4_ring_signal(lds_cnt_t p, int lane) {
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
     float* red = reinterpret_cast<float*>(smem);                       // [W][NC] sums of squares, then [NC] means
     float4* s_xq = reinterpret_cast<float4*>(red + W * NC + NC);       // [16] the tile's query points
     int* s_ri = reinterpret_cast<int*>(s_xq + 16) + 32;                // [ld] row -> point | component
-    lds_cnt_t ring_cnt = (lds_cnt_t)(reinterpret_cast<int*>(s_xq + 16));    // K4_RING: [0..3] tiles generated per slot, [8..11] wavefronts done per slot (cumulative)
+    lds_cnt_t ring_cnt = (lds_cnt_t)(reinterpret_cast<int*>(s_xq + 16));    // K4_RING: [0..3] tiles generated per slot, [8..11] wavefronts done per slot (cumulative), [15] a wait expired
     if (K4_RING && tid < 16) ring_cnt[tid] = 0;
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
     double* etab = reinterpret_cast<double*>(s_x4 + N);                // [N][16] exp table (optional)
@@ -283,9 +285,11 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
             const int nt = min(CB, cmax - c0 + 1);
             const int my_t = (((wave - pgci * CB) % W) + W) % W;
             if (my_t < nt) {
-                k4_ring_wait(ring_cnt + 8 + pslot, W * (pgci / NSLOT));
-                for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + my_t, qs, slot + (size_t)(my_t * QS + qs) * kTileFloats);
-                k4_ring_signal(ring_cnt + pslot, lane);
+                k4_ring_wait(ring_cnt + 8 + pslot, W * (pgci / NSLOT), ring_cnt + 15);
+                for (int t = my_t; t < nt; t += W) {      // (chunks wider than the workgroup has wavefronts: several tiles per wavefront)
+                    for (int qs = 0; qs < nset; ++qs) gen_tile(c0 + t, qs, slot + (size_t)(t * QS + qs) * kTileFloats);
+                    k4_ring_signal(ring_cnt + pslot, lane);
+                }
             }
             // (unconditional adds: an if / else chain over the three becomes a SELECT OF POINTERS to captured variables, and with it every
             // capture of the kernel's lambdas stays in scratch memory -- 240 allocas survived)
@@ -388,7 +392,7 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                 K4_LAP(0);
                 if (K4_RING) {      // chunk gci complete in its slot?  (its tiles were generated one or two chunks ago)
                     const int sl = gci % NSLOT;
-                    k4_ring_wait(ring_cnt + sl, sl == 0 ? exp_gen0 : (sl == 1 ? exp_gen1 : (sl == 2 ? exp_gen2 : exp_gen3)));
+                    k4_ring_wait(ring_cnt + sl, sl == 0 ? exp_gen0 : (sl == 1 ? exp_gen1 : (sl == 2 ? exp_gen2 : exp_gen3)), ring_cnt + 15);
                     K4_LAP(2);
                 }
                 {
@@ -507,8 +511,9 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                 var = (cq == 0) ? (float)(1.001 - (double)vs) : (float)((double)tos + 0.001 - (double)vs);
             else           // OnGPIS.cpp:235-237
                 var = (cq == 0) ? (float)(1.01 - (double)vs) : (float)((double)tos + 0.1 - (double)vs);
-            o[cq] = ms;
-            o[4 + cq] = var;
+            const bool ring_failed = K4_RING && ring_cnt[15] != 0;      // a bounded ring wait ran out (protocol error): poison, loudly
+            o[cq] = ring_failed ? __uint_as_float(0x7fc00000u) : ms;
+            o[4 + cq] = ring_failed ? __uint_as_float(0x7fc00000u) : var;
         }
     }
     K4_STAMP();
@@ -565,6 +570,8 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
         if (f0 + 4 * blk <= share || fixed + 2 * blk > hard) { use_table = 0; fixed = f0; }
     }
     if (fixed + nslot * blk > hard) return GPIS_ERR_LIMIT;
+    // (the small classes keep their occupancy: chunks of at least two / three column blocks at the price of fewer workgroups per CU
+    // measured 35 -> 30 / 24 % at K = 204, 17 -> 13 / 9 % at K = 102)
     const size_t budget = std::min(hard, std::max(share, fixed + nslot * blk));
     const int nblk = (int)((budget - fixed) / blk);           // column blocks the ring can hold
     int cb = std::max(1, std::min(nblk / nslot, 8));
