@@ -106,7 +106,8 @@ public:
     int last_train_jobs = 0, last_train_maxK = 0;
     long long last_eval_flops = 0;
     bool profile = false;
-    bool use_exp_table = true;   // K4: exp table in LDS when it fits (false: recompute per entry, the path large clusters take)
+    bool use_exp_table = true;   // K4 built with -DK4_RING=0 only (the barrier variant): exp table in LDS when it fits.  The shipped ring
+                                 // kernel never uses a table (every entry evaluates its own exponential): the flag is accepted and ignored
     bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
                                  // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
     int debug_inject = 0;        // test-only fault injection for the cooperative kernel (ongpis_train.hip, ctl[1])
@@ -237,7 +238,7 @@ struct EvalArgs {
     const int* job_q;        // query index per job (sorted by model)
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
-    int use_table;           // exp table in LDS (else recompute per entry); the launcher clears it when the table does not fit
+    int use_table;           // exp table in LDS (else recompute per entry); cleared by the launcher when the table does not fit -- always, in ring mode
     int cb;                  // column blocks per B chunk (set by ongpis_eval_launch from the LDS budget)
     int nslot;               // chunks in the LDS ring (2 or 3)
     unsigned long long* trace;   // instrumented builds only (tools/k4_ablate.sh); nullptr otherwise

@@ -183,8 +183,9 @@ int   gpis_ongpis_get_model(void* s, int model, float* L_ldxld, float* alpha_K, 
  * xq: nq*dim interleaved; out: njobs*8 = mean(4) var(4) (2-D uses 3+3, slots 3 and 7 unused) */
 int   gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs,
                        float* out8);
-/* K4 keeps one double-precision exp per (training point, query) in an LDS table when it fits; clusters too large
- * for that recompute it per entry.  on = 0 forces the second path for every cluster (results are identical). */
+/* Rounds 2-4: K4 kept one double-precision exp per (training point, query) in an LDS table when it fit.  The round-5 kernel
+ * (B chunks in a three-slot ring) spends that LDS on wider chunks and evaluates the exponential per entry for every cluster:
+ * the switch is accepted for compatibility and changes nothing (results were identical either way). */
 /* Packed model records for a multi-GPU exchange (what K4 needs from a trained model: 2 K^2 + 20 K bytes): pack the listed
  * models into d_buf (n records of `stride` bytes, stride >= gpis_ongpis_packed_bytes of every sender, a multiple of 256),
  * unpack records into predict-only models (models_inout[i] < 0: a new model is created and its id returned). */
