@@ -134,3 +134,24 @@ def test_default_mode_and_cu_reserve(monkeypatch):
     g1 = gpismap_amd.GPisMap3()
     s = g1.stats()
     assert s["pipelined"] == 1 and s["train_cu_reserve"] == 16
+
+
+def test_pool_cache_trim_returns_the_chunks_of_destroyed_maps():
+    """the chunks of destroyed pools are cached per device for the next map of the process; gpis_pool_cache_trim()
+    hands them back to the driver (bytes released > 0 after a map was destroyed, 0 when called again) and a map created
+    afterwards works as before."""
+    import gc
+    import gpismap_amd
+    grid = replay.synthetic_grid(16)
+    a = gpismap_amd.GPisMap3()
+    a.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    ref = a.test(grid).copy()
+    a.close()
+    del a
+    gc.collect()
+    released = gpismap_amd.pool_cache_trim()
+    assert released > 0 and released % (512 << 20) == 0
+    assert gpismap_amd.pool_cache_trim() == 0
+    b = gpismap_amd.GPisMap3()
+    b.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
+    assert np.array_equal(b.test(grid).view(np.uint32), ref.view(np.uint32))
