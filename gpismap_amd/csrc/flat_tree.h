@@ -291,8 +291,13 @@ public:
     int range_cells(const float* c, float h, CellLists& cl, std::vector<int>& ranges) const {
         cl.cells.clear();
         query_clusters(root, c, h, cl.cells, nullptr);
+        return range_cells_from(cl.cells, cl, ranges);
+    }
+    // ... with the cell walk done by the caller (the walks of a frame's clusters are independent and read-only: the map runs
+    // them on its host threads; the listing below stays in cluster order, so every offset is what the serial version gives)
+    int range_cells_from(const std::vector<int>& cells, CellLists& cl, std::vector<int>& ranges) const {
         int total = 0;
-        for (int cell : cl.cells) {
+        for (int cell : cells) {
             if (cl.begin[cell] < 0) {
                 cl.begin[cell] = (int)cl.pts.size();
                 all_points(cell, cl.pts);

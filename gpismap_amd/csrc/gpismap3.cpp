@@ -861,10 +861,39 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         int total = 0;
         if (rc == GPIS_OK && device_gather) {
             // K6 range part on the device: the host only names the cells (traversal order) and lists each touched cell once
-            for (int c : todo) {
+            // the cell walks of the frame's clusters on the host threads (read-only, independent), the listing in cluster order
+            std::vector<std::vector<int>> touched(todo.size());
+            pool().parallel_for((int)todo.size(), [&](int lo_, int hi_) {
+                for (int i = lo_; i < hi_; ++i) {
+                    const int c = todo[i];
+                    tree.query_clusters(tree.root, tree.nodes[c].c, tree.nodes[c].h * kRtimes, touched[i], nullptr);
+                }
+            }, 16);
+            {
+                // ... and so does listing every touched cell's points (a subtree walk per cell): the distinct cells in the order the
+                // serial pass would first meet them, their point lists in parallel, laid out back to back by a prefix sum --
+                // cell_lists then holds exactly what range_cells_from() would have built on the fly
+                std::vector<int> order;
+                for (const std::vector<int>& tc : touched)
+                    for (int cell : tc) if (cell_lists.begin[cell] == -1) { cell_lists.begin[cell] = -2; order.push_back(cell); }
+                std::vector<std::vector<int>> plist(order.size());
+                pool().parallel_for((int)order.size(), [&](int lo_, int hi_) {
+                    for (int i = lo_; i < hi_; ++i) tree.all_points(order[i], plist[i]);
+                }, 16);
+                size_t tot = cell_lists.pts.size();
+                for (const std::vector<int>& pl : plist) tot += pl.size();
+                cell_lists.pts.reserve(tot);
+                for (size_t i = 0; i < order.size(); ++i) {
+                    cell_lists.begin[order[i]] = (int)cell_lists.pts.size();
+                    cell_lists.pts.insert(cell_lists.pts.end(), plist[i].begin(), plist[i].end());
+                    cell_lists.end[order[i]] = (int)cell_lists.pts.size();
+                }
+            }
+            for (size_t ti = 0; ti < todo.size(); ++ti) {
+                const int c = todo[ti];
                 const float h = tree.nodes[c].h * kRtimes;
                 const int e0 = (int)cr.size() / 2;
-                const int capc = tree.range_cells(tree.nodes[c].c, h, cell_lists, cr);
+                const int capc = tree.range_cells_from(touched[ti], cell_lists, cr);
                 if (capc == 0) { cr.resize((size_t)2 * e0); continue; }      // no point in any touched cell: the reference's empty result
                 union { float f; int i; } u;
                 desc.push_back(e0); desc.push_back((int)cr.size() / 2 - e0); desc.push_back(total);
