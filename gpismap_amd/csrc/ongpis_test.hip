@@ -104,6 +104,7 @@ __device__ __forceinline__ void k4_ring_wait(lds_cnt_t p, int need, lds_cnt_t ex
     int spins = 0;
     for (; spins < (1 << 22); ++spins) {
         if (__builtin_amdgcn_readfirstlane(*p) >= need) break;
+        if ((spins & 1023) == 1023 && __builtin_amdgcn_readfirstlane(*expired) != 0) break;   // (a partner gave up already: one bounded wait per workgroup, not one per chunk)
         __builtin_amdgcn_s_sleep(1);
     }
     if (spins == (1 << 22)) *expired = 1;      // (a protocol error: the tile's results are written as NaN, never as plausible numbers)
