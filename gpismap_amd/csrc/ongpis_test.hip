@@ -432,11 +432,14 @@ __global__ __launch_bounds__(64 * W, K4_MINW) void ongpis_eval_kernel(EvalArgs A
                                 const int nbase = (b * (b + 1) / 2 + cn) * 4096;
 #pragma unroll
                                 for (int g = 0; g < 4; ++g) {
-                                    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+                                    float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), bq1 = make_float4(0.f, 0.f, 0.f, 0.f);
                                     if (K4_BT) bq = Bq[g];
+                                    if (K4_BT && QS == 2) { if (two) bq1 = Bq[g + kTileFloats / 4]; }       // (the second query set's tile follows the first)
 #pragma unroll
-                                    for (int j = 0; j < 4; ++j)
+                                    for (int j = 0; j < 4; ++j) {
                                         acc[t][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[4 * g + j], K4_BT ? (j == 0 ? bq.x : (j == 1 ? bq.y : (j == 2 ? bq.z : bq.w))) : Bl[(4 * g + j) * 2 * kTileStride], acc[t][0], 0, 0, 0);
+                                        if (QS == 2) { if (two) acc[t][QS - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[4 * g + j], K4_BT ? (j == 0 ? bq1.x : (j == 1 ? bq1.y : (j == 2 ? bq1.z : bq1.w))) : Bl[kTileFloats + (4 * g + j) * 2 * kTileStride], acc[t][QS - 1], 0, 0, 0); }
+                                    }
                                     auto q = __builtin_amdgcn_raw_buffer_load_b128(Xrs, Tvoff, nbase + g * 1024, 0);
                                     av1[4 * g + 0] = __uint_as_float(q[0]); av1[4 * g + 1] = __uint_as_float(q[1]);
                                     av1[4 * g + 2] = __uint_as_float(q[2]); av1[4 * g + 3] = __uint_as_float(q[3]);
