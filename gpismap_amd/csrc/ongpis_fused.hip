@@ -107,11 +107,12 @@ size_t ongpis_fused_lds_bytes(int nb) {
     return sizeof(float) * ((size_t)nb * (nb + 1) / 2 * 1024 + 256 + 256 + kRegion) + 256;   // + the flag words
 }
 
-// K6 gather + kernel matrix into the LDS tile slots (accumulator order, d_addr), the targets into yv; x4 / rowinfo (/ gidx) of
-// the model are written to global memory.  Shared by the two fused kernels; ends WITHOUT the closing barrier.
-__device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, const ClusterModel* __restrict__ mp, float* slots, float* yv, float* R,
-                                                   int job, int tid, int lane, int wave, int N, int ng, int K, int ld, int nb, int dim, int ntl) {
-    // ---------------------------------------------------------------- gather (K6)
+// K6 gather: the cluster's points into the phase-local region R (x4s, sig, gidx), the targets into yv; x4 / rowinfo (/ gidx) of the
+// model are written to global memory.  FT threads per workgroup (FT >= N).  Contains one workgroup barrier; the caller
+// synchronises before it reads R or yv.
+template <int FT>
+__device__ __forceinline__ void fused_gather(const FusedTrainArgs& A, const ClusterModel* __restrict__ mp, float* yv, float* R,
+                                             int job, int tid, int lane, int wave, int N, int ng, int K, int ld, int dim) {
     float4* x4s = reinterpret_cast<float4*>(R);              // [N]
     float* sig = R + 1024;                                   // [2 N] sigx' (after the 2.0 override), sigg
     int* gidx = reinterpret_cast<int*>(R + 1536);            // [N]
@@ -152,26 +153,26 @@ __device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, cons
                     mp->rowinfo[row] = tid | ((cc + 1) << 28);
                 }
         }
-        for (int r = K + tid; r < 256; r += kFT) yv[r] = 0.f;
-        for (int r = K + tid; r < ld; r += kFT) mp->rowinfo[r] = 0xF << 28;
+        for (int r = K + tid; r < 256; r += FT) yv[r] = 0.f;
+        for (int r = K + tid; r < ld; r += FT) mp->rowinfo[r] = 0xF << 28;
     }
-    FSTAMP(1);
-    // ---------------------------------------------------------------- kernel matrix into the LDS tiles
-    {
-        float4* z4 = reinterpret_cast<float4*>(slots);
-        for (int i = tid; i < ntl * 256; i += kFT) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    __syncthreads();
-    auto put = [&](int r, int c, float v) {   // lower triangle only (the pair is swapped into it)
-        const int rr = r >= c ? r : c, cc = r >= c ? c : r;
-        slots[tri_index(rr >> 5, cc >> 5) * 1024 + d_addr(rr & 31, cc & 31)] = v;   // accumulator order (see the Cholesky below)
-    };
+}
+
+// The kernel matrix of the gathered cluster, entry by entry of its lower triangle: put(row, col, value) (the pair is swapped
+// into the lower triangle first), every entry exactly once; the caller has zeroed its destination (structural zeros are not
+// all put).  One exp per point pair, evaluated in double: the formulas of ongpis_buildK_kernel.
+template <int FT, class Put>
+__device__ __forceinline__ void fused_build_entries(const ClusterModel* __restrict__ mp, const float* R, int tid, int N, int ng, int K, int nb, int dim, Put putl) {
+    const float4* x4s = reinterpret_cast<const float4*>(R);
+    const float* sig = R + 1024;
+    const int* gidx = reinterpret_cast<const int*>(R + 1536);
+    auto put = [&](int r, int c, float v) { putl(r >= c ? r : c, r >= c ? c : r, v); };
     {
         const float a = (float)(sqrt(3.0) / (double)mp->scale);  // covFnc.cpp:147
         const float a2 = a * a;
-        for (int r = K + tid; r < 32 * nb; r += kFT) put(r, r, 1.f);   // identity padding of the last block
+        for (int r = K + tid; r < 32 * nb; r += FT) put(r, r, 1.f);   // identity padding of the last block
         // diagonal pairs (k == k): cheap, one thread per point
-        for (int k = tid; k < N; k += kFT) {
+        for (int k = tid; k < N; k += FT) {
             const int kg = gidx[k];
             const int kind[3] = {N + kg, N + kg + ng, N + kg + 2 * ng};
             put(k, k, (float)(1.0 + (double)sig[k]));
@@ -192,7 +193,7 @@ __device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, cons
         // off-diagonal pairs k < j (one double-precision exp each): N (N - 1) / 2 of them, dealt evenly -- with the diagonal
         // pairs in the same list 64 points gave 2080 = 4 x 512 + 32 pairs: a fifth trip for everybody because of 32 lanes
         const int P = N * (N - 1) / 2;
-        for (int p = tid; p < P; p += kFT) {
+        for (int p = tid; p < P; p += FT) {
             int j = (int)((sqrtf(8.f * (float)p + 1.f) + 1.f) * 0.5f);      // p = j (j - 1) / 2 + k, k < j
             while (j * (j - 1) / 2 > p) --j;
             while ((j + 1) * j / 2 <= p) ++j;
@@ -223,6 +224,22 @@ __device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, cons
             }
         }
     }
+}
+
+// gather + kernel matrix into the LDS tile slots (accumulator order, d_addr) of the one-cluster-per-CU kernels; ends WITHOUT the
+// closing barrier.
+__device__ __forceinline__ void fused_gather_build(const FusedTrainArgs& A, const ClusterModel* __restrict__ mp, float* slots, float* yv, float* R,
+                                                   int job, int tid, int lane, int wave, int N, int ng, int K, int ld, int nb, int dim, int ntl) {
+    fused_gather<kFT>(A, mp, yv, R, job, tid, lane, wave, N, ng, K, ld, dim);
+    FSTAMP(1);
+    {
+        float4* z4 = reinterpret_cast<float4*>(slots);
+        for (int i = tid; i < ntl * 256; i += kFT) z4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+    fused_build_entries<kFT>(mp, R, tid, N, ng, K, nb, dim, [&](int rr, int cc, float v) {
+        slots[tri_index(rr >> 5, cc >> 5) * 1024 + d_addr(rr & 31, cc & 31)] = v;   // accumulator order (see the Cholesky below)
+    });
 }
 
 #ifndef V1_PRIO_DIAG
@@ -618,6 +635,7 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
 
 #ifdef GPIS_EXPERIMENTS
 #include "../../tools/experiments/ongpis_fused_df.inc"   // data-flow schedule of the same factorisation (measured slower)
+#include "../../tools/experiments/ongpis_fused_rp.inc"   // register-resident tiles, four wavefronts per cluster, two clusters per CU (measured equal)
 #endif
 
 int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hipStream_t s) {
@@ -629,11 +647,19 @@ int ongpis_launch_train_fused(const FusedTrainArgs& a, int njobs, int max_nb, hi
 #ifdef GPIS_EXPERIMENTS
     if (!small && getenv("GPIS_FUSED_DF") && atoi(getenv("GPIS_FUSED_DF"))) kern = (kern_t)ongpis_train_fused_df_kernel<2>;
 #endif
-    const size_t lds = ongpis_fused_lds_bytes(max_nb);
+    size_t lds = ongpis_fused_lds_bytes(max_nb);
+    int threads = kFT;
+#ifdef GPIS_EXPERIMENTS
+    const bool rp = !small && getenv("GPIS_FUSED_RP") && atoi(getenv("GPIS_FUSED_RP"));
+    if (rp) { kern = (kern_t)ongpis_train_fused_rp_kernel<2>; lds = ongpis_fused_rp_lds_bytes(); threads = kRT; }
+#endif
     if (ensure_dynamic_lds((const void*)kern, 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
-    hipLaunchKernelGGL(kern, dim3(njobs), dim3(kFT), lds, s, a);
+    hipLaunchKernelGGL(kern, dim3(njobs), dim3(threads), lds, s, a);
     GPIS_HIP(hipGetLastError());
 #ifdef GPIS_INSTRUMENT
+#ifdef GPIS_EXPERIMENTS
+    if (rp) rp_trace_dump(s); else
+#endif
     fused_trace_dump(s);
 #endif
     return GPIS_OK;

@@ -94,3 +94,46 @@ def test_async_factorisation_equals_barrier_kernel():
     o = oracle_lib.ongpis_train(dim, scale, pos[sel], grad[sel], val[sel], sx[sel], sg[sel])
     g = res[1][1][3]
     assert np.array_equal(np.tril(g["L"][:o["K"], :o["K"]]).view(np.uint32), np.tril(o["L"]).view(np.uint32))
+
+
+@pytest.mark.parametrize("dim,scale,sizes,nograd", [
+    (3, 0.04, [41, 48, 50, 56, 57, 63, 64], 0.0),       # K = 4 N: 6 .. 8 block rows, every tile of one type (generated in registers)
+    (3, 0.04, [75, 90, 107, 108, 112], 0.6),            # mixed gradient flags: tiles that straddle the type boundaries; 107 / 108: the pair-table limit
+    (3, 0.04, [170, 200, 224, 256], 1.0),               # value-only, K = N: the three-pass pair walk (no pair tables)
+    (2, 1.2, [60, 70, 85], 0.0),                        # 2-D: K = 3 N
+])
+def test_register_resident_training_equals_fused_kernel(dim, scale, sizes, nograd):
+    """Opt-in fused K3 with the tiles in registers, four wavefronts per cluster, two clusters per CU (ongpis_fused_rp.inc): factor,
+    alpha and predictions bit-identical to the shipped fused kernel and the oracle for clusters of 6 .. 8 block rows."""
+    import gpismap_amd
+    rng = np.random.default_rng(4242 + dim + len(sizes))
+    clusters = [make_cluster(rng, dim, n, scale, frac_nograd=nograd) for n in sizes]
+    pos = np.concatenate([c[0] for c in clusters]); grad = np.concatenate([c[1] for c in clusters])
+    val = np.concatenate([c[2] for c in clusters]); sx = np.concatenate([c[3] for c in clusters])
+    sg = np.concatenate([c[4] for c in clusters])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ids = np.arange(off[-1], dtype=np.int32)
+    P = soa9(dim, pos, grad, val, sx, sg)
+    nq = 19
+    xq = np.concatenate([pos[off[i]:off[i + 1]][rng.integers(0, sizes[i], nq)] + rng.normal(0, 0.3 * scale, (nq, dim))
+                         for i in range(len(sizes))]).astype(np.float32)
+    jq = np.arange(xq.shape[0], dtype=np.int32)
+    res = []
+    for rp in (False, True):
+        st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
+        os.environ["GPIS_FUSED_RP"] = "1" if rp else "0"
+        models = st.train(P, off, ids)
+        out = st.eval(xq, jq, np.repeat(models, nq).astype(np.int32)).copy()
+        res.append((out, [st.model(mm) for mm in models]))
+    os.environ["GPIS_FUSED_RP"] = "0"
+    assert np.array_equal(res[0][0].view(np.uint32), res[1][0].view(np.uint32))
+    for ci, n in enumerate(sizes):
+        a, b = res[0][1][ci], res[1][1][ci]
+        K = a["K"]
+        assert K <= 256 and (K + 31) // 32 >= 6, (n, K)
+        assert np.array_equal(np.tril(a["L"][:K, :K]).view(np.uint32), np.tril(b["L"][:K, :K]).view(np.uint32)), n
+        assert np.array_equal(a["alpha"].view(np.uint32), b["alpha"].view(np.uint32)), n
+    sel = ids[off[1]:off[2]]
+    o = oracle_lib.ongpis_train(dim, scale, pos[sel], grad[sel], val[sel], sx[sel], sg[sel])
+    g = res[1][1][1]
+    assert np.array_equal(np.tril(g["L"][:o["K"], :o["K"]]).view(np.uint32), np.tril(o["L"]).view(np.uint32))
