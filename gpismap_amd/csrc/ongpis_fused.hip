@@ -550,9 +550,19 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int cr = 32 * c;
                 const float* tile = slots + tri_index(c, r) * 1024;
+                // the operands of four steps are requested together, ahead of the steps' branches: a step that is its own basic
+                // block waits for its two LDS operands in full (measured on the register-resident variant, NOTEBOOK R5.9: 400
+                // cycles per step against 130).  Rows >= K - cr are padding (the last row block only; yv holds zeros there).
+                const int kv = K - cr;
 #pragma unroll
-                for (int k = 31; k >= 0; --k)
-                    if (cr + k < K) s = fmaf(-tile[a_addr(k, l31)], yv[cr + k], s);
+                for (int kg = 7; kg >= 0; --kg) {
+                    float tl[4], ak[4];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) { tl[jj] = tile[a_addr(4 * kg + jj, l31)]; ak[jj] = yv[cr + 4 * kg + jj]; }
+#pragma unroll
+                    for (int jj = 3; jj >= 0; --jj)
+                        if (4 * kg + jj < kv) s = fmaf(-tl[jj], ak[jj], s);
+                }
             }
             const float* Dc = slots + tri_index(r, r) * 1024;
             float dcol[32];

@@ -243,13 +243,14 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
             for (int q = 0; q < 8; ++q) { dcol[4 * q] = dq[q].x; dcol[4 * q + 1] = dq[q].y; dcol[4 * q + 2] = dq[q].z; dcol[4 * q + 3] = dq[q].w; }
             float b = (cr + l31 < K) ? yv[cr + l31] : 0.f;
             const float dd = (cr + l31 < K) ? dg : 1.f;
+            // (selects, no branch per step: rows >= kv are the padding of the last block)
+            const int kv = K - cr;
 #pragma unroll
             for (int k = 31; k >= 0; --k) {
-                if (cr + k >= K) continue;
                 const float t = b / dd;
                 const float ak = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), k));
-                if (l31 == k) b = ak;
-                if (l31 < k) b = fmaf(-dcol[k], ak, b);
+                const float nb_ = (l31 == k) ? ak : ((l31 < k) ? fmaf(-dcol[k], ak, b) : b);
+                b = (k < kv) ? nb_ : b;
             }
             if (lane < 32) {
                 av[lane] = (cr + lane < K) ? b : 0.f;
