@@ -68,8 +68,9 @@ struct GPisMap::Impl {
     long stat_obs_queries = 0, stat_clusters_trained = 0, stat_late = 0;
 
     explicit Impl(const GPisMapParam& par)
-        : setting(par), tree(tree_param2()), store(2, par.map_scale_param),
+        : tree(tree_param2()), store(2, par.map_scale_param),
           mq(2, (float)((double)par.map_scale_param * 4.0), 0.4f, (float)(1.0 + (double)par.map_noise_param)) {
+        setting = par;      // assignment: the public struct's only copy constructor takes a non-const reference (as the reference's)
         ok = (hipGetDevice(&device) == hipSuccess) && (hipStreamCreate(&stream) == hipSuccess);
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap: no usable HIP device; update()/test() will fail\n");

@@ -188,8 +188,9 @@ struct GPisMap3::Impl {
     static constexpr int kQueryBlock = 65536;
 
     Impl(const GPisMap3Param& par, const camParam& c)
-        : setting(par), cam(c), tree(tree_param3()), store(3, par.map_scale_param),
+        : cam(c), tree(tree_param3()), store(3, par.map_scale_param),
           mq(3, (float)((double)kCleng * 3.0), 0.5f, (float)(1.0 + (double)par.map_noise_param)) {
+        setting = par;      // assignment: the public struct's only copy constructor takes a non-const reference (as the reference's)
         int pr_least = 0, pr_greatest = 0;
         ok = (hipGetDevice(&device) == hipSuccess) && (hipDeviceGetStreamPriorityRange(&pr_least, &pr_greatest) == hipSuccess) &&
              (hipStreamCreateWithPriority(&stream, hipStreamDefault, pr_greatest) == hipSuccess) &&
@@ -1122,7 +1123,7 @@ GPisMap3* gpis3_impl_create_on(const GPisMap3Param& par, const camParam& c, cons
     for (int d : devs) if (d < 0 || d >= ndev) return nullptr;
     try { return new GPisMap3(par, c, devs.data(), n); } catch (...) { return nullptr; }
 }
-GPisMap3::GPisMap3(GPisMap3Param par, camParam c, const int* devices, int n)
+GPisMap3::GPisMap3(const GPisMap3Param& par, camParam c, const int* devices, int n)
     : p_(make_impl(par, c, std::vector<int>(devices, devices + n))) {}
 
 template <class F>

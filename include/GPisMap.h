@@ -44,6 +44,19 @@ typedef struct GPisMapParam_ {
         map_scale_param = 1.2;
         map_noise_param = 1e-2;
     }
+    /* The reference declares this copy constructor (cpp/include/GPisMap.h:56-66, non-const reference); it decides the calling
+     * convention of GPisMap(GPisMapParam) (hidden pointer instead of 44 bytes on the stack), see include/GPisMap3.h.  The
+     * reference's body leaves angle_obs_limit of the copy uninitialised; here it is copied as well:
+     * a caller that sets the limits gets them, a caller that never touches them sees the same defaults either way. */
+    GPisMapParam_(GPisMapParam_& par)
+        : delx(par.delx), fbias(par.fbias), obs_var_thre(par.obs_var_thre),
+          min_position_noise(par.min_position_noise), min_grad_noise(par.min_grad_noise),
+          map_scale_param(par.map_scale_param), map_noise_param(par.map_noise_param) {
+        sensor_offset[0] = par.sensor_offset[0];
+        sensor_offset[1] = par.sensor_offset[1];
+        angle_obs_limit[0] = par.angle_obs_limit[0];
+        angle_obs_limit[1] = par.angle_obs_limit[1];
+    }
 } GPisMapParam;
 
 class GPisMap {

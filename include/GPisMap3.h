@@ -65,6 +65,15 @@ typedef struct GPisMap3Param_ {
         map_scale_param = 0.04;
         map_noise_param = 5e-3;
     }
+    /* The reference declares this copy constructor (cpp/include/GPisMap3.h:71-80, non-const reference).  It is part of the ABI: a
+     * user-provided copy constructor makes the struct non-trivial for calls, so GPisMap3(GPisMap3Param) and
+     * GPisMap3(GPisMap3Param, camParam) receive `par` through a hidden pointer to a caller-made copy.  Without it the same
+     * mangled constructors would expect 32 bytes on the stack and an object compiled against the reference's header would
+     * link and pass garbage (tests/cpp/dropin_demo.cpp asserts the property and the field offsets). */
+    GPisMap3Param_(GPisMap3Param_& par)
+        : delx(par.delx), fbias(par.fbias), obs_var_thre(par.obs_var_thre), obs_skip(par.obs_skip),
+          min_position_noise(par.min_position_noise), min_grad_noise(par.min_grad_noise),
+          map_scale_param(par.map_scale_param), map_noise_param(par.map_noise_param) {}
 } GPisMap3Param;
 
 class GPisMap3 {
@@ -82,7 +91,7 @@ public:
 
     /* Extensions (not in the reference): device-resident queries, introspection, several devices behind one object
      * (GPIS_DEVICES=0,1,... in the environment, or the device-list constructor / gpis3_create_multi). */
-    GPisMap3(GPisMap3Param par, camParam c, const int* devices, int n);
+    GPisMap3(const GPisMap3Param& par, camParam c, const int* devices, int n);
     void update_one(float* dataz, int N, std::vector<float>& pose);   /* this object's own device only */
     bool test_one(float* x, int dim, int leng, float* res);
     bool testDevice(const float* d_x, int leng, float* d_res, void* hip_stream);

@@ -3,11 +3,45 @@
 // gateways' own flags (-std=c++11 -pthread -fPIC) against the library instead of the reference sources.
 // Output: one line per check, parsed by tests/test_host.py (build) and tests/test_gpu_dropin.py (run).
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 #include "GPisMap.h"
 #include "GPisMap3.h"
+
+// ---- ABI of the by-value public structs --------------------------------------------------------------------
+// The reference gives both parameter structs a user-provided copy constructor taking a NON-CONST reference
+// (cpp/include/GPisMap3.h:71-80, cpp/include/GPisMap.h:56-66).  That makes them non-trivial for the purposes of calls: the
+// constructors GPisMap3(GPisMap3Param), GPisMap3(GPisMap3Param, camParam) and GPisMap(GPisMapParam) take `par` through a hidden
+// pointer to a caller-made copy.  A header without the copy constructors would produce the same mangled names with a different
+// calling convention (the struct in registers / on the stack), so these properties are part of the drop-in surface.
+static_assert(!std::is_trivially_copy_constructible<GPisMap3Param>::value, "reference cpp/include/GPisMap3.h:71-80");
+static_assert(!std::is_trivially_copyable<GPisMap3Param>::value, "reference cpp/include/GPisMap3.h:71-80");
+static_assert(!std::is_constructible<GPisMap3Param, const GPisMap3Param&>::value, "the reference's copy constructor binds lvalues only");
+static_assert(!std::is_trivially_copy_constructible<GPisMapParam>::value, "reference cpp/include/GPisMap.h:56-66");
+static_assert(!std::is_trivially_copyable<GPisMapParam>::value, "reference cpp/include/GPisMap.h:56-66");
+// camParam has no user-provided copy constructor in the reference (cpp/include/GPisMap3.h:29-46): trivially copyable, by value
+static_assert(std::is_trivially_copy_constructible<camParam>::value, "reference cpp/include/GPisMap3.h:29-46");
+// field order / offsets / sizes: reference cpp/include/GPisMap3.h:30-35, :49-59 and cpp/include/GPisMap.h:30-42.  offsetof on
+// these (standard-layout, non-POD because of the constructors) types is conditionally supported; g++ and clang accept it.
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+static_assert(std::is_standard_layout<camParam>::value && std::is_standard_layout<GPisMap3Param>::value &&
+              std::is_standard_layout<GPisMapParam>::value, "plain structs");
+static_assert(sizeof(camParam) == 24 && offsetof(camParam, fx) == 0 && offsetof(camParam, fy) == 4 && offsetof(camParam, cx) == 8 &&
+              offsetof(camParam, cy) == 12 && offsetof(camParam, width) == 16 && offsetof(camParam, height) == 20, "camParam layout");
+static_assert(sizeof(GPisMap3Param) == 32 && offsetof(GPisMap3Param, delx) == 0 && offsetof(GPisMap3Param, fbias) == 4 &&
+              offsetof(GPisMap3Param, obs_var_thre) == 8 && offsetof(GPisMap3Param, obs_skip) == 12 &&
+              offsetof(GPisMap3Param, min_position_noise) == 16 && offsetof(GPisMap3Param, min_grad_noise) == 20 &&
+              offsetof(GPisMap3Param, map_scale_param) == 24 && offsetof(GPisMap3Param, map_noise_param) == 28, "GPisMap3Param layout");
+static_assert(sizeof(GPisMapParam) == 44 && offsetof(GPisMapParam, delx) == 0 && offsetof(GPisMapParam, fbias) == 4 &&
+              offsetof(GPisMapParam, sensor_offset) == 8 && offsetof(GPisMapParam, angle_obs_limit) == 16 &&
+              offsetof(GPisMapParam, obs_var_thre) == 24 && offsetof(GPisMapParam, min_position_noise) == 28 &&
+              offsetof(GPisMapParam, min_grad_noise) == 32 && offsetof(GPisMapParam, map_scale_param) == 36 &&
+              offsetof(GPisMapParam, map_noise_param) == 40, "GPisMapParam layout");
+#pragma GCC diagnostic pop
 
 static unsigned checksum(const std::vector<float>& v) {
     unsigned c = 2166136261u;
@@ -30,7 +64,8 @@ int main(int argc, char** argv) {
     const char* dir = argc > 1 ? argv[1] : 0;   // optional: inputs written by the test (depth0/1.bin, x.bin, th/rg/x2.bin)
     // ---- 3-D: 'setCamera' + 'update' x2 + 'test' + 'getAllPoints' + 'reset' ----
     camParam c(568.0f, 568.0f, 310.0f, 224.0f, 640, 480);
-    GPisMap3* gpm = new GPisMap3(GPisMap3Param(), c);
+    GPisMap3Param p3;                          // an lvalue, as mexGPisMap3.cpp:133-140 passes it (the copy constructor binds nothing else)
+    GPisMap3* gpm = new GPisMap3(p3, c);
     const int W = 640, H = 480;
     std::vector<float> depth((size_t)W * H);
     std::vector<float> pose = {0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -64,6 +99,13 @@ int main(int argc, char** argv) {
     delete gpm;
 
     // ---- 2-D: 'update' + 'test' + 'reset' ----
+    {   // the by-value constructor once (GPisMap.cpp:69), then the default one like mexGPisMap.cpp:43
+        GPisMapParam p2;
+        p2.angle_obs_limit[0] = -2.0f;
+        GPisMap* gtmp = new GPisMap(p2);
+        std::printf("map2_by_value %d\n", gtmp->getMapDimension());
+        delete gtmp;
+    }
     GPisMap* g2 = new GPisMap();
     std::printf("map_dimension %d\n", g2->getMapDimension());
     const int NB = 270;
