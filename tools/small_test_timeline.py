@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """A small test() call (24^3 points, the size of the demo grids) on the F = 5 synthetic map: wall time per call; run under
-rocprofv3 --kernel-trace (tools/test_timeline.sh) for the kernels behind it."""
+rocprofv3 --kernel-trace (tools/small_test_timeline.sh) for the kernels behind it."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
