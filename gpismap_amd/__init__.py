@@ -105,6 +105,9 @@ def lib():
     L.gpis_ongpis_set_exp_table.argtypes = [vp, C.c_int]
     L.gpis_ongpis_kernel_matrix.argtypes = [vp, fp, ip, fp, fp, C.c_int, fp]
     L.gpis_ongpis_set_debug.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "gpis_selftest_ranged_arith"):       # (A/B runs load older builds of the library through GPISMAP_AMD_LIB)
+        L.gpis_selftest_ranged_arith.argtypes = [C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+        L.gpis_selftest_ranged_arith.restype = C.c_int
     L.gpis_ongpis_set_keep_factor.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_fused.argtypes = [vp, C.c_int]
     L.gpis_ongpis_set_lazy_inverse.argtypes = [vp, C.c_int]
@@ -112,6 +115,14 @@ def lib():
     L.gpis3_set_lazy_inverse.argtypes = [vp, C.c_int]
     _lib = L
     return L
+
+
+def selftest_ranged_arith(seed=1, blocks=1024, per_thread=64, mode=0):
+    """gpis_selftest_ranged_arith: (square-root mismatches, division mismatches) of blocks * 256 * per_thread operand pairs run
+    through the factorisation kernels' range-restricted sqrt / division and through the compiler's IEEE ones on the device."""
+    m = (C.c_ulonglong * 2)(0, 0)
+    _check(lib().gpis_selftest_ranged_arith(int(seed), int(blocks), int(per_thread), int(mode), m), "gpis_selftest_ranged_arith")
+    return int(m[0]), int(m[1])
 
 
 def pool_cache_trim():
@@ -448,13 +459,17 @@ class OnGPIS:
         _check(self.L.gpis_ongpis_get_model(self.h, int(slot), _p(Lm), _p(alpha), _p(gidx, C.c_int)), "gpis_ongpis_get_model")
         return dict(N=N, ng=ng, K=K, ld=ld, L=Lm.T.copy(), alpha=alpha, gidx=gidx)  # L[r, c]
 
-    def eval(self, xq, job_q, job_model):
+    def eval(self, xq, job_q, job_model, return_status=False):
+        """return_status=True: (status, out) instead of raising -- GPIS_ERR_STATE (-3, the kernels' error word) still delivers
+        `out`, with the affected results NaN."""
         xq = np.ascontiguousarray(xq, dtype=np.float32)
         job_q = np.ascontiguousarray(job_q, dtype=np.int32)
         job_model = np.ascontiguousarray(job_model, dtype=np.int32)
         out = np.zeros((job_q.size, 8), dtype=np.float32)
-        _check(self.L.gpis_ongpis_eval(self.h, _p(xq), xq.shape[0], _p(job_q, C.c_int), _p(job_model, C.c_int), job_q.size,
-                                       _p(out)), "gpis_ongpis_eval")
+        rc = self.L.gpis_ongpis_eval(self.h, _p(xq), xq.shape[0], _p(job_q, C.c_int), _p(job_model, C.c_int), job_q.size, _p(out))
+        if return_status:
+            return int(rc), out
+        _check(rc, "gpis_ongpis_eval")
         return out
 
     def packed_bytes(self, models):
@@ -484,7 +499,8 @@ class OnGPIS:
         return out.reshape(K, K).T.copy()
 
     def set_debug(self, inject=0, wait_limit_ms=0):
-        """Bound of the in-kernel waits (0 = default 2 s) and the test-only fault injection of the cooperative kernel."""
+        """Bound of the in-kernel waits (0 = default 2 s) and the test-only fault injection: inject bit 0 = the cooperative
+        factorisation withholds a hand-over, bit 4 (16) = the first workgroup of every prediction launch withholds one ring signal."""
         _check(self.L.gpis_ongpis_set_debug(self.h, int(inject), int(wait_limit_ms)), "gpis_ongpis_set_debug")
 
     def set_lazy_inverse(self, on=True):

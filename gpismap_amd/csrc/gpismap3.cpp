@@ -10,6 +10,8 @@
 // are handled by an on-demand batch when that cluster is reached.
 #include <algorithm>
 #include <thread>
+#include <string>
+#include <unistd.h>
 #include <cstdlib>
 #include <array>
 #include <cmath>
@@ -221,8 +223,12 @@ struct GPisMap3::Impl {
     // Pipelined update: the training of frame f runs beside the host work and the ObsGP batches of frame f + 1.  A factorisation
     // workgroup holds its CU for milliseconds and nothing pre-empts it, so the training streams are kept off
     // `pipeline_reserve` CUs (spread evenly over the XCDs): the ObsGP kernels -- highest priority, unmasked -- start at once
-    // there (measured, tools/ubench/cumask_probe.hip: 6 us instead of 2 ms beside a busy unmasked stream).
-    int pipeline_reserve = 32;
+    // there (measured, tools/ubench/cumask_probe.hip: 6 us instead of 2 ms beside a busy unmasked stream).  Round 6: a quarter of
+    // the device (64 CUs) instead of an eighth -- the next frame's large K2 batches (stored points x 7 queries, the pixel batch)
+    // run on the reserved CUs only while a training is in flight, and on 32 of them they took 2.4 ms where the idle device takes
+    // 1.0; pipelined frames 2..6 of the synthetic sequence, one call, reserve 32 / 64 / 96: 10.0-13.7 / 8.7-11.5 / 8.3-11.4 ms,
+    // per frame with the drain charged 14.0-15.0 / 12.1-12.4 / 13.1-13.3 ms (the drain grows with the reserve: 11.6 / 12.4 / 13.7 ms).
+    int pipeline_reserve = 64;
     bool pipeline_reserve_set = false;
     // What the caller asked for (gpis3_set_pipeline / GPIS_PIPELINE_UPDATE) and what is in force: a map that shards its training over
     // ranks or devices trains synchronously (every frame ends with the exchange) and sets no CUs aside, whatever was asked; the
@@ -235,7 +241,7 @@ struct GPisMap3::Impl {
         if (on) {
             int ncu = 0;
             (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device);
-            want = pipeline_reserve_set ? pipeline_reserve : std::min(pipeline_reserve, ncu / 8);    // default: an eighth of the device, at most 32 CUs
+            want = pipeline_reserve_set ? pipeline_reserve : std::min(pipeline_reserve, ncu / 4);    // default: a quarter of the device, at most 64 CUs
         }
         if (want != store.cu_reserve()) {
             (void)store.set_cu_reserve(want);
@@ -964,12 +970,15 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     // beside the lead's share.
                     std::vector<int> wrc(1 + peers.size(), GPIS_OK);
                     std::vector<std::thread> th;
+                    const int rc0 = rc;       // (the lead's rc is written below while the workers run: they look at a copy)
                     for (size_t r = 1; r <= peers.size(); ++r)
-                        th.emplace_back([&, r] {
+                        th.emplace_back([&, r, rc0] {
                             Impl& w = *peers[r - 1]->impl();
                             DeviceScope ds(w.device);
+                            // (job list and pending table as on the lead, failed frame or not: the exchange that follows builds every
+                            // rank's table from the lead's index either way)
                             w.shard_jobs = shard_jobs; w.table_pending = true; w.has_tree = true; w.upd_rc = 0;
-                            if (rc != GPIS_OK) return;
+                            if (rc0 != GPIS_OK) return;
                             std::vector<TrainJob> wj;
                             for (size_t j = 0; j < jobs.size(); ++j) if (owner[j] == (int)r) wj.push_back(jobs[j]);
                             int q = w.store.upload_points(mirror_soa.data(), (int)np_mirror, w.train_stream);
@@ -1259,6 +1268,27 @@ void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     }
 } catch (const std::exception& e) { nothrow_report("GPisMap3::update", e.what()); p_->upd_rc = GPIS_ERR_STATE; } catch (...) { nothrow_report("GPisMap3::update", "unknown exception"); p_->upd_rc = GPIS_ERR_STATE; }
 
+// Several devices behind one map: a device that had to drop models (error word of a training or inverse pass -- with factor
+// records every receiver inverts for itself, so ONE rank can lose models its owner still holds) must not leave test() answers
+// depending on which rank evaluates a block.  The union of what any rank dropped is dropped everywhere and every table is
+// rebuilt; the status surfaces on the lead (upd_rc), as a failed training does.
+static void reconcile_dropped(GPisMap3::Impl& m) {
+    if (m.peers.empty()) { (void)m.store.take_dropped(); return; }
+    std::vector<int> all = m.store.take_dropped();
+    for (GPisMap3* q : m.peers) { std::vector<int> d = q->impl()->store.take_dropped(); all.insert(all.end(), d.begin(), d.end()); }
+    if (all.empty()) return;
+    std::sort(all.begin(), all.end());
+    all.erase(std::unique(all.begin(), all.end()), all.end());
+    fprintf(stderr, "[gpismap_amd] %d models dropped on one device are dropped on every device of the map\n", (int)all.size());
+    if (!m.upd_rc) m.upd_rc = GPIS_ERR_STATE;
+    for_each_rank(m, [&](int r, GPisMap3* q) {
+        GPisMap3::Impl& w = r == 0 ? m : *q->impl();
+        DeviceScope ds(w.device);
+        (void)w.store.drop_models(all, w.stream);
+        if (!w.table_pending) w.build_cluster_table();
+    });
+}
+
 bool GPisMap3::testDevice(const float* d_x, int leng, float* d_res, void* hip_stream) try {
     DeviceScope dev_scope_(p_->device);
     Impl& m = *p_;
@@ -1319,6 +1349,7 @@ bool GPisMap3::test(float* x, int dim, int leng, float* res) try {  // GPisMap3.
             o += (size_t)(hi - lo);
         }
     });
+    reconcile_dropped(m0);
     for (int r = 0; r < world; ++r) if (!okv[r]) { p_->fail_rc = frc[r]; return false; }
     return true;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::test", e.what()); p_->fail_rc = GPIS_ERR_STATE; return false; } catch (...) { nothrow_report("GPisMap3::test", "unknown exception"); p_->fail_rc = GPIS_ERR_STATE; return false; }
@@ -1387,10 +1418,10 @@ struct CkptHeader {
     unsigned version, dim, sz_node, sz_point, sz_param;
     int root, has_tree;
     unsigned long long n_nodes, n_pts, n_free_nodes, n_free_pts, n_pending, n_models, model_bytes;
-    unsigned long long checksum;     // FNV-1a (64 bit) over every byte that follows the header
+    unsigned long long checksum;     // FNV-1a (64 bit) over the header (this field zero) and every byte that follows it
 };
-const char kCkptMagic[8] = {'G', 'P', 'I', 'S', '3', 'C', 'K', '2'};
-constexpr unsigned kCkptVersion = 2;
+const char kCkptMagic[8] = {'G', 'P', 'I', 'S', '3', 'C', 'K', '3'};
+constexpr unsigned kCkptVersion = 3;
 struct Fnv64 {
     unsigned long long h = 1469598103934665603ull;
     void add(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } }
@@ -1435,8 +1466,64 @@ bool ckpt_tree_consistent(const std::vector<FlatTree<3>::TNode>& nodes, const st
         if (!(t.h > 0.f)) return false;
     }
     if (has_tree && (root < 0 || root >= nn || !nodes[root].alive || nodes[root].par != -1)) return false;
+    // every live node hangs off the root within a bounded depth (parent and child links agree, see above, so a walk down the
+    // child links from the root finds exactly the nodes whose parent chain ends at the root): a cycle of live nodes beside the
+    // tree, or a crafted chain deep enough to overflow the recursive walks over the index, is refused here
+    {
+        constexpr int kMaxDepth = 64;       // (max_half / min_half = 2^8 in the product's geometry)
+        std::vector<int> depth((size_t)nn, -1), stack;
+        size_t reached = 0, live = 0;
+        for (int i = 0; i < nn; ++i) live += nodes[i].alive ? 1 : 0;
+        if (has_tree) { depth[root] = 0; stack.push_back(root); }
+        while (!stack.empty()) {
+            const int i = stack.back(); stack.pop_back();
+            ++reached;
+            if (nodes[i].leaf) continue;
+            for (int k = 0; k < FlatTree<3>::NC; ++k) {
+                const int c = nodes[i].ch[k];
+                if (c < 0) continue;
+                if (depth[c] >= 0 || depth[i] + 1 > kMaxDepth) return false;
+                depth[c] = depth[i] + 1;
+                stack.push_back(c);
+            }
+        }
+        if (reached != live) return false;
+    }
     for (int c : cells) if (c < 0 || c >= nn || !nodes[c].alive) return false;
     return true;
+}
+// A checkpoint read and validated on the host, before anything of it touches a map.
+struct CkptImage {
+    CkptHeader h;
+    std::vector<FlatTree<3>::TNode> nodes; std::vector<FlatPoint<3>> pts;
+    std::vector<int> free_nodes, free_pts, pending, cells;
+    std::vector<unsigned long long> offs;
+    std::vector<char> bytes;
+};
+bool ckpt_read(const char* path, const FlatTreeParam& q, CkptImage& im) {
+    FILE* f = fopen(path, "rb");
+    if (!f) return false;
+    struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
+    CkptHeader& h = im.h;
+    FlatTreeParam prm;
+    Fnv64 ck;
+    if (fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != kCkptVersion || h.dim != 3 ||
+        h.sz_node != sizeof(FlatTree<3>::TNode) || h.sz_point != sizeof(FlatPoint<3>) || h.sz_param != sizeof(FlatTreeParam)) return false;
+    { CkptHeader h0 = h; h0.checksum = 0; ck.add(&h0, sizeof(h0)); }
+    // another tree geometry (field by field: the struct has padding)
+    if (fread(&prm, sizeof(prm), 1, f) != 1) return false;
+    ck.add(&prm, sizeof(prm));
+    if (prm.init_half != q.init_half || prm.min_half != q.min_half || prm.min_half_sq != q.min_half_sq ||
+        prm.max_half != q.max_half || prm.cluster_half != q.cluster_half || prm.cluster_eps != q.cluster_eps ||
+        prm.qleaf_eps_plain != q.qleaf_eps_plain || prm.qleaf_eps_dist != q.qleaf_eps_dist || prm.qdesc_eps != q.qdesc_eps) return false;
+    const unsigned long long lim = 1ull << 31;
+    if (h.n_nodes >= lim || h.n_pts >= lim || h.n_free_nodes > h.n_nodes || h.n_free_pts > h.n_pts || h.n_pending > h.n_pts || h.n_models > h.n_nodes) return false;
+    if (!rd_vec(f, im.nodes, (size_t)h.n_nodes, ck) || !rd_vec(f, im.pts, (size_t)h.n_pts, ck) || !rd_vec(f, im.free_nodes, (size_t)h.n_free_nodes, ck) ||
+        !rd_vec(f, im.free_pts, (size_t)h.n_free_pts, ck) || !rd_vec(f, im.pending, (size_t)h.n_pending, ck) || !rd_vec(f, im.cells, (size_t)h.n_models, ck) ||
+        !rd_vec(f, im.offs, (size_t)h.n_models + 1, ck) || im.offs.back() != h.model_bytes || !rd_vec(f, im.bytes, (size_t)h.model_bytes, ck)) return false;
+    if (ck.h != h.checksum) return false;       // damaged header or payload
+    for (size_t i = 0; i + 1 < im.offs.size(); ++i) if (im.offs[i] > im.offs[i + 1]) return false;
+    return ckpt_tree_consistent(im.nodes, im.pts, im.free_nodes, im.free_pts, im.pending, im.cells, h.root, h.has_tree != 0);
 }
 }  // namespace
 
@@ -1468,7 +1555,10 @@ bool GPisMap3::saveMap(const char* path) try {
         (void)hipFree(d_buf);
         if (rc != GPIS_OK) return false;
     }
-    FILE* f = fopen(path, "wb");
+    // written beside the target and renamed over it once complete: a failed save (disk full, pack error) leaves the previous
+    // checkpoint of that name intact
+    const std::string tmp_path = std::string(path) + ".tmp";
+    FILE* f = fopen(tmp_path.c_str(), "wb");
     if (!f) return false;
     CkptHeader h;
     std::memset(&h, 0, sizeof(h));
@@ -1509,82 +1599,58 @@ bool GPisMap3::saveMap(const char* path) try {
     }
     Fnv64 ck;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;      // (rewritten below with the checksum)
+    ck.add(&h, sizeof(h));                           // (checksum field still zero)
     ck.add(&pimg_prm, sizeof(pimg_prm));
     ok = ok && fwrite(&pimg_prm, sizeof(FlatTreeParam), 1, f) == 1 &&
          wr_vec(f, nimg, ck) && wr_vec(f, pimg, ck) && wr_vec(f, m.tree.free_nodes, ck) && wr_vec(f, m.tree.free_pts, ck) &&
          wr_vec(f, m.tree.pending_free_pts, ck) && wr_vec(f, cells, ck) && wr_vec(f, offs, ck) && wr_vec(f, bytes, ck);
     h.checksum = ck.h;
     ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof(h), 1, f) == 1;
+    ok = ok && fflush(f) == 0 && fsync(fileno(f)) == 0;
     ok = (fclose(f) == 0) && ok;
-    if (!ok) (void)remove(path);      // never leave a half-written checkpoint behind
+    ok = ok && rename(tmp_path.c_str(), path) == 0;
+    if (!ok) (void)remove(tmp_path.c_str());      // never leave a half-written file behind; the target is untouched
     return ok;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::saveMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::saveMap", "unknown exception"); return false; }
 
-bool GPisMap3::loadMap(const char* path) try {
-    if (p_->peers.empty() || p_->shard_rank != 0) return loadMap_one(path);
-    // several devices behind one map: every device keeps a full copy of the models -- each rank loads the file
-    // (the lead first: the workers build their cluster tables from ITS index)
-    if (!loadMap_one(path)) return false;
-    std::vector<int> okv(1 + p_->peers.size(), 1);
-    for_each_rank(*p_, [&](int r, GPisMap3* q) { if (r > 0) okv[r] = q->loadMap_one(path) ? 1 : 0; });
-    for (int v : okv) if (!v) return false;
-    return true;
-} catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
-
-bool GPisMap3::loadMap_one(const char* path) try {
-    Impl& m = *p_;
-    if (!path || !m.ok) return false;
+// loadMap in three steps.  (1) The file is read and validated on the host, once (ckpt_read).  (2) STAGE: every device unpacks
+// the records into NEW slots of its live store; until that has succeeded everywhere the map is untouched, and a failure on
+// any device releases what the call created on every device.  Several devices behind one map: the workers' cluster tables are
+// built from the LEAD's index, which names the lead's slots -- the slot ids every device obtained must be the lead's, and
+// this is checked, not assumed (a divergent free list is a refused load, not a test() that reads the wrong models).
+// (3) COMMIT (cannot fail half-way across devices: nothing in it allocates): the models the stores held before go back to
+// them, the lead swaps the index in -- a worker's own tree stays empty -- and every device builds its cluster table.
+namespace {
+int ckpt_stage(GPisMap3::Impl& m, const CkptImage& im, std::vector<int>& slots) {
     DeviceScope ds(m.device);
-    FILE* f = fopen(path, "rb");
-    if (!f) return false;
-    struct Closer { FILE* f; ~Closer() { if (f) fclose(f); } } closer{f};
-    CkptHeader h;
-    FlatTreeParam prm;
-    Fnv64 ck;
-    if (fread(&h, sizeof(h), 1, f) != 1 || std::memcmp(h.magic, kCkptMagic, 8) != 0 || h.version != kCkptVersion || h.dim != 3 ||
-        h.sz_node != sizeof(FlatTree<3>::TNode) || h.sz_point != sizeof(FlatPoint<3>) || h.sz_param != sizeof(FlatTreeParam)) return false;
-    {   // another tree geometry (field by field: the struct has padding)
-        const FlatTreeParam& q = m.tree.prm;
-        if (fread(&prm, sizeof(prm), 1, f) != 1) return false;
-        ck.add(&prm, sizeof(prm));
-        if (prm.init_half != q.init_half || prm.min_half != q.min_half || prm.min_half_sq != q.min_half_sq ||
-            prm.max_half != q.max_half || prm.cluster_half != q.cluster_half || prm.cluster_eps != q.cluster_eps ||
-            prm.qleaf_eps_plain != q.qleaf_eps_plain || prm.qleaf_eps_dist != q.qleaf_eps_dist || prm.qdesc_eps != q.qdesc_eps) return false;
-    }
-    const unsigned long long lim = 1ull << 31;
-    if (h.n_nodes >= lim || h.n_pts >= lim || h.n_free_nodes > h.n_nodes || h.n_free_pts > h.n_pts || h.n_pending > h.n_pts || h.n_models > h.n_nodes) return false;
-    std::vector<FlatTree<3>::TNode> nodes; std::vector<FlatPoint<3>> pts;
-    std::vector<int> free_nodes, free_pts, pending, cells;
-    std::vector<unsigned long long> offs;
-    std::vector<char> bytes;
-    if (!rd_vec(f, nodes, (size_t)h.n_nodes, ck) || !rd_vec(f, pts, (size_t)h.n_pts, ck) || !rd_vec(f, free_nodes, (size_t)h.n_free_nodes, ck) ||
-        !rd_vec(f, free_pts, (size_t)h.n_free_pts, ck) || !rd_vec(f, pending, (size_t)h.n_pending, ck) || !rd_vec(f, cells, (size_t)h.n_models, ck) ||
-        !rd_vec(f, offs, (size_t)h.n_models + 1, ck) || offs.back() != h.model_bytes || !rd_vec(f, bytes, (size_t)h.model_bytes, ck)) return false;
-    if (ck.h != h.checksum) return false;       // damaged payload
-    for (size_t i = 0; i + 1 < offs.size(); ++i) if (offs[i] > offs[i + 1]) return false;
-    if (!ckpt_tree_consistent(nodes, pts, free_nodes, free_pts, pending, cells, h.root, h.has_tree != 0)) return false;
-    // The file is consistent.  The models are unpacked into NEW slots of the live store first: until that has succeeded the map
-    // is untouched, and a failure releases what the call created (unpack_models) and leaves the map as it was.
     (void)m.finish_training();
-    const std::vector<int> old_slots = m.store.live_slots();
-    std::vector<int> slots(cells.size(), -1);
-    if (!cells.empty()) {
-        int rc = GPIS_OK;
-        void* d_buf = nullptr;
-        if (hipMalloc(&d_buf, bytes.size()) != hipSuccess) rc = GPIS_ERR_HIP;
-        if (rc == GPIS_OK && hipMemcpy(d_buf, bytes.data(), bytes.size(), hipMemcpyHostToDevice) != hipSuccess) rc = GPIS_ERR_HIP;
-        std::vector<size_t> o(offs.begin(), offs.end());
-        if (rc == GPIS_OK) rc = m.store.unpack_models(d_buf, (int)cells.size(), 0, slots.data(), m.stream, o.data());
-        if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
-        if (d_buf) (void)hipFree(d_buf);
-        if (rc != GPIS_OK) {
-            for (int sl : slots) if (sl >= 0) m.store.release_slot(sl);
-            (void)hipGetLastError();
-            return false;
-        }
+    slots.assign(im.cells.size(), -1);
+    if (im.cells.empty()) return GPIS_OK;
+    int rc = GPIS_OK;
+    void* d_buf = nullptr;
+    if (hipMalloc(&d_buf, im.bytes.size()) != hipSuccess) rc = GPIS_ERR_HIP;
+    if (rc == GPIS_OK && hipMemcpy(d_buf, im.bytes.data(), im.bytes.size(), hipMemcpyHostToDevice) != hipSuccess) rc = GPIS_ERR_HIP;
+    std::vector<size_t> o(im.offs.begin(), im.offs.end());
+    if (rc == GPIS_OK) rc = m.store.unpack_models(d_buf, (int)im.cells.size(), 0, slots.data(), m.stream, o.data());
+    if (rc == GPIS_OK && hipStreamSynchronize(m.stream) != hipSuccess) rc = GPIS_ERR_HIP;
+    if (d_buf) (void)hipFree(d_buf);
+    if (rc != GPIS_OK) {
+        for (int& sl : slots) { if (sl >= 0) m.store.release_slot(sl); sl = -1; }
+        (void)hipGetLastError();
     }
-    // replace the map: the models the store held before the call go back to it one by one (the new ones live in the same store;
-    // by slot, not by walking the tree: a device worker's models hang off the lead's tree)
+    return rc;
+}
+void ckpt_unstage(GPisMap3::Impl& m, std::vector<int>& slots) {
+    DeviceScope ds(m.device);
+    for (int& sl : slots) { if (sl >= 0) m.store.release_slot(sl); sl = -1; }
+    // devices that got further than others before the refusal hold different free lists now; in ascending order every store
+    // hands out the same ids again (ids a store never created lie above all of its free ones)
+    m.store.canonical_free_slots();
+}
+void ckpt_commit(GPisMap3::Impl& m, CkptImage* im /* the lead's: swapped in; nullptr on a worker */, const std::vector<int>& old_slots,
+                 const std::vector<int>& cells, const std::vector<int>& slots) {
+    DeviceScope ds(m.device);
+    // (by slot, not by walking the tree: a device worker's models hang off the lead's tree)
     for (int sl : old_slots) m.store.release_slot(sl);
     m.upd_rc = 0;
     m.tree.clear(); m.has_tree = false;
@@ -1592,12 +1658,65 @@ bool GPisMap3::loadMap_one(const char* path) try {
     m.obs_numdata = 0;
     m.activeSet.clear();
     m.shard_jobs.clear(); m.table_pending = false;
-    for (FlatTree<3>::TNode& t : nodes) t.model = -1;
-    m.tree.nodes.swap(nodes); m.tree.pts.swap(pts); m.tree.free_nodes.swap(free_nodes); m.tree.free_pts.swap(free_pts);
-    m.tree.pending_free_pts.swap(pending); m.tree.released_models.clear();
-    m.tree.root = h.has_tree ? h.root : -1; m.tree.last_cell = -1;
-    m.has_tree = h.has_tree != 0;
+    if (!im) return;
+    for (FlatTree<3>::TNode& t : im->nodes) t.model = -1;
+    m.tree.nodes.swap(im->nodes); m.tree.pts.swap(im->pts); m.tree.free_nodes.swap(im->free_nodes); m.tree.free_pts.swap(im->free_pts);
+    m.tree.pending_free_pts.swap(im->pending); m.tree.released_models.clear();
+    m.tree.root = im->h.has_tree ? im->h.root : -1; m.tree.last_cell = -1;
+    m.has_tree = im->h.has_tree != 0;
     for (size_t i = 0; i < cells.size(); ++i) m.tree.nodes[cells[i]].model = slots[i];
+}
+}  // namespace
+
+bool GPisMap3::loadMap(const char* path) try {
+    if (p_->peers.empty() || p_->shard_rank != 0) return loadMap_one(path);
+    Impl& m = *p_;
+    if (!path || !m.ok) return false;
+    CkptImage im;
+    if (!ckpt_read(path, m.tree.prm, im)) return false;
+    const int world = 1 + (int)m.peers.size();
+    auto rank_impl = [&](int r) -> Impl& { return r == 0 ? m : *m.peers[r - 1]->impl(); };
+    std::vector<std::vector<int>> old_slots(world), slots(world);
+    std::vector<int> rcv(world, GPIS_OK);
+    for_each_rank(m, [&](int r, GPisMap3*) {
+        Impl& w = rank_impl(r);
+        DeviceScope ds(w.device);
+        (void)w.finish_training();
+        old_slots[r] = w.store.live_slots();
+        rcv[r] = ckpt_stage(w, im, slots[r]);
+    });
+    bool ok = true;
+    for (int r = 0; r < world; ++r) ok = ok && rcv[r] == GPIS_OK && slots[r] == slots[0];
+    if (!ok) {
+        for (int r = 0; r < world; ++r)
+            if (rcv[r] == GPIS_OK && slots[r] != slots[0]) { fprintf(stderr, "[gpismap_amd] loadMap: model slots of the devices diverged; the map is kept as it was\n"); break; }
+        for_each_rank(m, [&](int r, GPisMap3*) { ckpt_unstage(rank_impl(r), slots[r]); });
+        return false;
+    }
+    const std::vector<int> cells = im.cells;
+    ckpt_commit(m, &im, old_slots[0], cells, slots[0]);          // the lead's index first: the workers' tables are built from it
+    for_each_rank(m, [&](int r, GPisMap3*) {
+        Impl& w = rank_impl(r);
+        if (r > 0) ckpt_commit(w, nullptr, old_slots[r], cells, slots[r]);
+        DeviceScope ds(w.device);
+        w.build_cluster_table();
+    });
+    for (int r = 0; r < world; ++r) if (rank_impl(r).upd_rc != 0) return false;
+    return true;
+} catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
+
+bool GPisMap3::loadMap_one(const char* path) try {
+    Impl& m = *p_;
+    if (!path || !m.ok) return false;
+    DeviceScope ds(m.device);
+    CkptImage im;
+    if (!ckpt_read(path, m.tree.prm, im)) return false;
+    (void)m.finish_training();
+    const std::vector<int> old_slots = m.store.live_slots();
+    std::vector<int> slots;
+    if (ckpt_stage(m, im, slots) != GPIS_OK) return false;
+    const std::vector<int> cells = im.cells;
+    ckpt_commit(m, &im, old_slots, cells, slots);
     m.build_cluster_table();
     return m.upd_rc == 0;
 } catch (const std::exception& e) { nothrow_report("GPisMap3::loadMap", e.what()); return false; } catch (...) { nothrow_report("GPisMap3::loadMap", "unknown exception"); return false; }
@@ -1710,6 +1829,7 @@ int gpis3_impl_prepare_test(GPisMap3* g) {
     const int rc = m.store.ensure_inverses(m.stream);
     if (rc && !m.upd_rc) m.upd_rc = rc;
     if (rc == GPIS_ERR_STATE && !m.table_pending) m.build_cluster_table();
+    if (!m.lead) reconcile_dropped(m);
     return m.upd_rc;
 }
 void gpis3_impl_set_lazy_inverse(GPisMap3* g, int on) {

@@ -561,7 +561,7 @@ int MapQuery::eval_pass(OnGPISStore& store, int njobs, int shift, int rec_base, 
         EvalArgs a;
         a.models = store.d_models(); a.xq = d_xq_;
         a.tile_model = t_model + tot[8 + c]; a.tile_off = t_off + tot[8 + c]; a.tile_cnt = t_cnt + tot[8 + c];
-        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.use_table = 1; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        a.job_q = d_jq_; a.job_out = d_jo_; a.out = d_out_; a.cb = 0; a.debug = store.debug_inject; a.err = store.eval_err(); a.trace = nullptr;
         hipStream_t st = s;
         if (fork && nlaunched > 0) {
             const int i = (nlaunched - 1) % kSide;
@@ -646,6 +646,11 @@ int MapQuery::run(OnGPISStore& store, const float* d_x, int n, float* d_res, hip
         if (rc) return rc;
     }
     GPIS_HIP(hipStreamSynchronize(s));
+    if (const int ew = store.take_eval_err()) {
+        // (a ring wait of K4 expired: a protocol error.  The affected queries carry NaN; the call fails instead of handing them out.)
+        fprintf(stderr, "[gpismap_amd] prediction kernels reported error word 0x%x (a ring wait expired): the affected results are NaN\n", ew);
+        return GPIS_ERR_STATE;
+    }
     return GPIS_OK;
 }
 

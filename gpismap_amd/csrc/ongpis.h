@@ -61,6 +61,9 @@ public:
     // allocate an empty slot / release it (cluster node destroyed)
     int new_slot();
     void release_slot(int slot);
+    int drop_models(const std::vector<int>& slots, hipStream_t s);    // mark untrained (memory back to the pool)
+    std::vector<int> take_dropped() { std::vector<int> v; v.swap(dropped_); return v; }   // models dropped by failed training / inverse passes since the last call
+    void canonical_free_slots();    // free ids handed out in ascending order from now on (stores mirrored across devices re-align after a refused load)
     void clear();
     // Upload the point mirror (host SoA rows of length n, 9 rows).
     int upload_points(const float* soa9, int n, hipStream_t s);
@@ -106,11 +109,15 @@ public:
     int last_train_jobs = 0, last_train_maxK = 0;
     long long last_eval_flops = 0;
     bool profile = false;
-    bool use_exp_table = true;   // K4 built with -DK4_RING=0 only (the barrier variant): exp table in LDS when it fits.  The shipped ring
-                                 // kernel never uses a table (every entry evaluates its own exponential): the flag is accepted and ignored
+    bool use_exp_table = true;   // accepted and ignored: K4 evaluates the exponential per entry since round 5 (an exp table in LDS cost ring width,
+                                 // one in global memory -- round 6 -- a memory round trip per generated tile: both measured slower)
     bool keep_factor = false;    // models of at most ONGPIS_FUSED_MAX_K rows are trained on chip and keep only what K4 reads
                                  // (rowinfo, x4, Xt); true: they also receive L, alpha, gidx (parity tests, gpis_ongpis_get_model)
-    int debug_inject = 0;        // test-only fault injection for the cooperative kernel (ongpis_train.hip, ctl[1])
+    int debug_inject = 0;        // test-only fault injection: bits 0..3 the cooperative kernel (ongpis_train.hip, ctl[1]), bit 4 the ring of K4
+    // Error word of the prediction kernels: page-locked host memory the kernels raise bits in (nothing is written in a healthy
+    // launch); the caller that synchronises the launch stream reads and clears it (take_eval_err).
+    int* eval_err();
+    int take_eval_err() { if (!h_eval_err_) return 0; const int v = *(volatile int*)h_eval_err_; *(volatile int*)h_eval_err_ = 0; return v; }
     int wait_limit_ticks = 0;    // bound of the in-kernel waits in 100 MHz ticks (0: 2 s)
     bool use_fused = true;       // false: every cluster takes the separate gather / build / factorise / invert kernels
     // Pipelined training: train_batch() returns once the kernels are enqueued (on the caller's stream and the side streams)
@@ -154,6 +161,8 @@ private:
     void mark_stale(int slot) { if ((int)xstale_.size() < (int)models_.size()) xstale_.resize(models_.size(), 0); xstale_[slot] = 1; stale_list_.push_back(slot); }
     std::vector<char> xstale_;                   // per slot: the factor is newer than Xt (lazy inverse)
     std::vector<int> stale_list_;                // slots marked since the last ensure_inverses()
+    int* h_eval_err_ = nullptr;
+    std::vector<int> dropped_;                   // slots whose models an error word made this store drop (take_dropped)
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
     int train_enqueue(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
     int coop_dev_ = 0, coop_held_ = 0;           // cooperative workgroups this store holds of its device's budget (batch in flight)
@@ -238,9 +247,9 @@ struct EvalArgs {
     const int* job_q;        // query index per job (sorted by model)
     const int* job_out;      // output record per job
     float* out;              // [records][8]: mean(4) var(4)  (2-D uses 3+3, slots 3 and 7 unused)
-    int use_table;           // exp table in LDS (else recompute per entry); cleared by the launcher when the table does not fit -- always, in ring mode
     int cb;                  // column blocks per B chunk (set by ongpis_eval_launch from the LDS budget)
-    int nslot;               // chunks in the LDS ring (2 or 3)
+    int debug;               // test hooks (gpis_ongpis_set_debug): bit 4 = one ring signal of the launch's first workgroup is withheld
+    int* err;                // error word of the store (page-locked host memory, OnGPISStore::eval_err): bit 0 = a ring wait of K4 expired
     unsigned long long* trace;   // instrumented builds only (tools/k4_ablate.sh); nullptr otherwise
 };
 // K4 size classes by nbx = ld / 32 = ceil((K+1)/32) block rows: W = 1, 2, 4 wavefronts per workgroup for nbx <= 4, 8, 16

@@ -66,7 +66,7 @@ __device__ __forceinline__ void diag_solve8(f32x16& v, const float* Lc, int h) {
     for (int i = I0; i < I0 + 8; ++i) {
         if (i + 1 < I0 + 8) diag_load(nxt, Lc, i + 1, h);
         const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
-        float cand = v[ri] / cur.d;
+        float cand = div_ranged(v[ri], cur.d, cur.r);
         unsigned cu = __float_as_uint(cand);
         auto sw = __builtin_amdgcn_permlane32_swap(cu, cu, false, false);
         float vi = __uint_as_float(hi_ ? sw[1] : sw[0]);
@@ -314,7 +314,8 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 const int k = k0 + kk;
-                const float cand = zs / Lc[k * 32 + k];
+                const float dk = Lc[k * 32 + k];
+                const float cand = div_ranged(zs, dk, rcp_refined(dk));      // (the diagonal entry and its reciprocal are off the chain)
                 const float zk = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cand), k));
                 const float lik = Lc[k * 32 + l31];
                 zs = (l31 == k) ? zk : ((l31 > k) ? fmaf(-lik, zk, zs) : zs);
@@ -570,10 +571,11 @@ __global__ __launch_bounds__(kFT, MINW) void ongpis_train_fused_kernel(FusedTrai
             for (int k = 0; k < 32; ++k) dcol[k] = Dc[d_addr(l31, k)];     // L_rr[k][l31] for k > l31 (other entries unused)
             float b = (rr + l31 < K) ? s : 0.f;
             const float dd = (rr + l31 < K) ? Ldiag[rr + l31] : 1.f;
+            const float ddr = rcp_refined(dd);
 #pragma unroll
             for (int k = 31; k >= 0; --k) {
                 if (rr + k >= K) continue;
-                const float t = b / dd;
+                const float t = div_ranged(b, dd, ddr);
                 const float ak = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), k));
                 if (l31 == k) b = ak;
                 if (l31 < k) b = fmaf(-dcol[k], ak, b);

@@ -3,6 +3,7 @@
 // entry (K4) used by the kernel-level C-ABI and the parity tests.
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <numeric>
@@ -85,6 +86,7 @@ int OnGPISStore::set_cu_reserve(int n) {
 OnGPISStore::~OnGPISStore() {
     clear();
     if (h_err_) (void)hipHostFree(h_err_);
+    if (h_eval_err_) (void)hipHostFree(h_eval_err_);
     (void)hipFree(d_models_); (void)hipFree(pts_.d); (void)hipFree(d_ids_); (void)hipFree(d_jobs_); (void)hipFree(d_work_); (void)hipFree(d_cwork_); (void)hipFree(d_ej_); (void)hipFree(d_err_); (void)hipFree(d_slots_); (void)hipFree(d_rg_);
     if (ev0_) (void)hipEventDestroy(ev0_);
     if (ev1_) (void)hipEventDestroy(ev1_);
@@ -101,7 +103,7 @@ void OnGPISStore::clear() {
     for (size_t i = 0; i < models_.size(); ++i)
         if (live_[i]) free_model_mem(models_[i]);
     models_.clear(); live_.clear(); free_slots_.clear();
-    xstale_.clear(); stale_list_.clear();
+    xstale_.clear(); stale_list_.clear(); dropped_.clear();
     dirty_ = true;
 }
 
@@ -125,6 +127,34 @@ void OnGPISStore::release_slot(int s) {
     free_slots_.push_back(s);
     dirty_ = true;
 }
+
+// Mark models untrained (their cells answer test() with the prior): used to bring the stores of several devices behind one
+// map back in step after ONE of them had to drop models (an inverse pass of imported factors that reported an error word).
+int OnGPISStore::drop_models(const std::vector<int>& slots, hipStream_t s) {
+    (void)train_finish();
+    bool any = false;
+    for (int slot : slots) {
+        if (slot < 0 || slot >= (int)models_.size() || !live_[slot] || !models_[slot].base) continue;
+        ClusterModel& m = models_[slot];
+        free_model_mem(m);
+        std::memset(&m, 0, sizeof(ClusterModel));
+        if (slot < (int)xstale_.size()) xstale_[slot] = 0;
+        any = true;
+    }
+    if (!any) return GPIS_OK;
+    dirty_ = true;
+    return sync_models(s);
+}
+
+int* OnGPISStore::eval_err() {
+    if (!h_eval_err_) {
+        if (hipHostMalloc((void**)&h_eval_err_, 64, hipHostMallocMapped) != hipSuccess) { h_eval_err_ = nullptr; return nullptr; }
+        *h_eval_err_ = 0;
+    }
+    return h_eval_err_;
+}
+
+void OnGPISStore::canonical_free_slots() { std::sort(free_slots_.begin(), free_slots_.end(), std::greater<int>()); }
 
 size_t OnGPISStore::device_bytes() const { return pool_bytes(pool_); }
 
@@ -470,6 +500,7 @@ int OnGPISStore::ensure_inverses(hipStream_t s) {
             ClusterModel& m = models_[slot];
             free_model_mem(m);
             std::memset(&m, 0, sizeof(ClusterModel));
+            dropped_.push_back(slot);
         }
         dirty_ = true;
         (void)sync_models(s);
@@ -731,6 +762,8 @@ int OnGPISStore::train_finish() {
             ClusterModel& m = models_[slot];
             free_model_mem(m);
             std::memset(&m, 0, sizeof(ClusterModel));
+            if (slot < (int)xstale_.size()) xstale_[slot] = 0;     // (no factor left that an inverse could be computed from)
+            dropped_.push_back(slot);
         }
         dirty_ = true;
         (void)sync_models(pend_stream_);
@@ -978,13 +1011,17 @@ int OnGPISStore::eval_jobs(const float* d_xq4, const int* h_job_q, const int* h_
         EvalArgs a;
         a.models = d_models_; a.xq = reinterpret_cast<const float4*>(d_xq4);
         a.tile_model = d_t + base[c]; a.tile_off = d_t + base[c] + nt; a.tile_cnt = d_t + base[c] + 2 * nt;
-        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.use_table = use_exp_table ? 1 : 0; a.cb = 0; a.nslot = 0; a.trace = nullptr;
+        a.job_q = d_jq; a.job_out = d_jo; a.out = d_out; a.cb = 0; a.debug = debug_inject; a.err = eval_err(); a.trace = nullptr;
         rc = ongpis_eval_launch(c, nt, maxN[c], maxLd[c], a, s);
         if (rc) return rc;
     }
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     GPIS_HIP(hipStreamSynchronize(s));
     if (profile) GPIS_HIP(hipEventElapsedTime(&last_eval_ms, ev0_, ev1_));
+    if (const int ew = take_eval_err()) {
+        fprintf(stderr, "[gpismap_amd] prediction kernels reported error word 0x%x (a ring wait expired): the affected results are NaN\n", ew);
+        return GPIS_ERR_STATE;
+    }
     return GPIS_OK;
 }
 

@@ -243,11 +243,12 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
             for (int q = 0; q < 8; ++q) { dcol[4 * q] = dq[q].x; dcol[4 * q + 1] = dq[q].y; dcol[4 * q + 2] = dq[q].z; dcol[4 * q + 3] = dq[q].w; }
             float b = (cr + l31 < K) ? yv[cr + l31] : 0.f;
             const float dd = (cr + l31 < K) ? dg : 1.f;
+            const float ddr = rcp_refined(dd);
             // (selects, no branch per step: rows >= kv are the padding of the last block)
             const int kv = K - cr;
 #pragma unroll
             for (int k = 31; k >= 0; --k) {
-                const float t = b / dd;
+                const float t = div_ranged(b, dd, ddr);
                 const float ak = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), k));
                 const float nb_ = (l31 == k) ? ak : ((l31 < k) ? fmaf(-dcol[k], ak, b) : b);
                 b = (k < kv) ? nb_ : b;

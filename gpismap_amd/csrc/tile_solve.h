@@ -7,6 +7,44 @@ namespace gpis {
 
 __device__ __forceinline__ int rowmap_t(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// ---- square root and division of the factorisation chains (round 6) --------------------------------------------------------
+// A pivot step of the Cholesky sweeps is ONE dependent chain: update -> broadcast -> sqrtf -> divide -> update ... .  The
+// compiler's correctly rounded sqrtf and `/` spend most of their ~30 dependent instructions on operand ranges these chains never
+// see: sqrtf scales arguments below 2^-96 and classifies zeros / infinities, `/` runs v_div_scale twice, v_div_fmas and
+// v_div_fixup around a seven-instruction core (reciprocal estimate, one Newton step on it, quotient estimate, two residual
+// corrections).  Both cores are reproduced here WITHOUT the range handling -- the same instructions on the same values, hence
+// the same bits, whenever the scaling would not have triggered: arguments of the square root in [2^-96, 2^128), divisors whose
+// reciprocal is normal, numerators that are zero or at least 2^-100 in magnitude with quotients inside the normal range.
+// Pivots of these matrices are square roots of diagonal Schur complements of kernel matrices with diagonal 1 + sigma or
+// 3 / s^2 + sigma (in (0, ~1.9e3]; a matrix that has lost positive definiteness yields NaN here as there), the numerators are sums
+// of products of kernel entries (|.| <= 1.9e3; the non-zero ones are no smaller than an ulp of such products: nowhere near 2^-100).
+// Zero numerators keep their sign and 0 / 0 stays NaN (the fix-up instruction's job).  The divisor-only part of a division -- the refined
+// reciprocal -- is computed ONCE per divisor, off the chain where the divisor is known ahead (diagonal solves, substitutions).
+// tests/test_gpu_ongpis.py::test_ranged_sqrt_and_division_equal_the_ieee_ones runs gpis_selftest_ranged_arith (millions of
+// operand pairs in and around the ranges above against the compiler's own sqrtf and `/` on the device); every factor, alpha
+// and prediction test compares the kernels with the oracle's IEEE sqrtf and `/` bit for bit.
+__device__ __forceinline__ float sqrt_ranged(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);                                   // v_sqrt_f32: within one ulp
+    const float sm = __uint_as_float(__float_as_uint(s) - 1u), sp = __uint_as_float(__float_as_uint(s) + 1u);
+    const float rm = fmaf(-sm, s, x), rp = fmaf(-sp, s, x);                     // residuals of the neighbours
+    float t = (0.f >= rm) ? sm : s;
+    t = (0.f < rp) ? sp : t;
+    return t;
+}
+__device__ __forceinline__ float rcp_refined(float d) {                          // the divisor-only part of a / d
+    const float r = __builtin_amdgcn_rcpf(d);                                    // v_rcp_f32: within one ulp
+    const float e = fmaf(-d, r, 1.0f);
+    return fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_ranged(float a, float d, float r) {         // a / d with r = rcp_refined(d)
+    const float q0 = a * r;
+    float e = fmaf(-d, q0, a);
+    float q = fmaf(e, r, q0);
+    e = fmaf(-d, q, a);
+    q = fmaf(e, r, q);
+    return (a == 0.f) ? q0 : q;             // (+-0 / d: the zero of the right sign -- and NaN for 0 / 0, where r is NaN -- is the first product)
+}
+
 // In-register solve of the 32x32 lower-triangular system for the 32 columns of a
 // tile held in MFMA C/D layout (lane = column, 16 of the 32 rows per lane half).
 // Lc = diagonal block of L, column-major in LDS.  Row i is finalised by the half
@@ -14,13 +52,14 @@ __device__ __forceinline__ int rowmap_t(int r, int h) { return (r & 3) + 8 * (r 
 // row gets one fmaf: ascending chain, identical to the unblocked order.
 // Column i of the block is fetched as four 16-byte LDS reads per lane half (rows
 // 8g+4h .. 8g+4h+3), software-pipelined one step ahead.
-struct DiagCol { float4 g[4]; float d; };
+struct DiagCol { float4 g[4]; float d, r; };
 __device__ __forceinline__ void diag_load(DiagCol& c, const float* Lc, int i, int h) {
     const float4* p = reinterpret_cast<const float4*>(Lc + i * 32 + 4 * h);
 #pragma unroll
     for (int g = 0; g < 4; ++g)
         if (8 * g + 7 > i) c.g[g] = p[2 * g];  // compile-time prune (i is a constant after unrolling)
     c.d = Lc[i * 32 + i];
+    c.r = rcp_refined(c.d);        // (off the chain: the column is fetched one step ahead of its use)
 }
 template <bool PIPE>
 __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) {
@@ -30,7 +69,7 @@ __device__ __forceinline__ void diag_solve32(f32x16& v, const float* Lc, int h) 
     for (int i = 0; i < 32; ++i) {
         if (PIPE && i + 1 < 32) diag_load(nxt, Lc, i + 1, h);
         const int hi_ = (i >> 2) & 1, ri = (i & 3) + 4 * (i >> 3);
-        float cand = v[ri] / cur.d;
+        float cand = div_ranged(v[ri], cur.d, cur.r);
         // broadcast row i from the half that owns it: v_permlane32_swap gives {low-half copy, high-half copy}
         unsigned cu = __float_as_uint(cand);
         auto sw = __builtin_amdgcn_permlane32_swap(cu, cu, false, false);
@@ -62,8 +101,8 @@ __device__ __forceinline__ int tri_index(int b, int c) { return b * (b + 1) / 2 
 // current step: same operations in an order that lets the dependent sqrt/divide chain overlap the broadcasts and fmas
 // (measured: no difference in kernel time on either the stress or the frame workload -- kept as the single shared copy).
 __device__ __forceinline__ void factor32_inreg(float (&a)[32], int row) {
-    float d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[0]), 0)));
-    float lic = a[0] / d;
+    float d = sqrt_ranged(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[0]), 0)));
+    float lic = div_ranged(a[0], d, rcp_refined(d));
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
         a[c] = (row == c) ? d : lic;
@@ -72,8 +111,8 @@ __device__ __forceinline__ void factor32_inreg(float (&a)[32], int row) {
         if (c + 1 < 32) {
             const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c]), c + 1));
             a[c + 1] = fmaf(nl, lk1, a[c + 1]);
-            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c + 1]), c + 1)));
-            licn = a[c + 1] / dn;
+            dn = sqrt_ranged(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[c + 1]), c + 1)));
+            licn = div_ranged(a[c + 1], dn, rcp_refined(dn));
         }
 #pragma unroll
         for (int k = c + 2; k < 32; ++k) {
@@ -108,8 +147,8 @@ __device__ __forceinline__ void factor32_mb(f32x16& t, int row, int h, int lane,
     float a8[8];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { a8[i] = lo_half(t[4 * M + i]); a8[4 + i] = hi_half(t[4 * M + i]); }   // columns 8M .. 8M+7 of row `row`
-    float d = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[0]), 8 * M)));
-    float lic = a8[0] / d;
+    float d = sqrt_ranged(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[0]), 8 * M)));
+    float lic = div_ranged(a8[0], d, rcp_refined(d));
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const int col = 8 * M + c;
@@ -120,8 +159,8 @@ __device__ __forceinline__ void factor32_mb(f32x16& t, int row, int h, int lane,
         if (c + 1 < 8) {
             const float lk1 = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c]), col + 1));
             a8[c + 1] = fmaf(nl, lk1, a8[c + 1]);
-            dn = sqrtf(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c + 1]), col + 1)));
-            licn = a8[c + 1] / dn;
+            dn = sqrt_ranged(__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a8[c + 1]), col + 1)));
+            licn = div_ranged(a8[c + 1], dn, rcp_refined(dn));
         }
 #pragma unroll
         for (int k = c + 2; k < 8; ++k) {

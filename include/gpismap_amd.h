@@ -183,9 +183,9 @@ int   gpis_ongpis_get_model(void* s, int model, float* L_ldxld, float* alpha_K, 
  * xq: nq*dim interleaved; out: njobs*8 = mean(4) var(4) (2-D uses 3+3, slots 3 and 7 unused) */
 int   gpis_ongpis_eval(void* s, const float* xq, int nq, const int* job_q, const int* job_model, int njobs,
                        float* out8);
-/* Rounds 2-4: K4 kept one double-precision exp per (training point, query) in an LDS table when it fit.  The round-5 kernel
+/* Rounds 2-4: K4 kept one double-precision exp per (training point, query) in an LDS table when it fit.  The kernel since round 5
  * (B chunks in a three-slot ring) spends that LDS on wider chunks and evaluates the exponential per entry for every cluster:
- * the switch is accepted for compatibility and changes nothing (results were identical either way). */
+ * gpis_ongpis_set_exp_table is accepted for compatibility and changes nothing (results were identical either way). */
 /* Packed model records for a multi-GPU exchange (what K4 needs from a trained model: 2 K^2 + 20 K bytes): pack the listed
  * models into d_buf (n records of `stride` bytes, stride >= gpis_ongpis_packed_bytes of every sender, a multiple of 256),
  * unpack records into predict-only models (models_inout[i] < 0: a new model is created and its id returned). */
@@ -210,9 +210,17 @@ int   gpis_ongpis_set_fused(void* s, int on);
 int   gpis_ongpis_set_lazy_inverse(void* s, int on);
 /* In-kernel waits (the cooperative factorisation of the largest clusters, the pipelined inverse) are bounded: when one
  * expires the batch's models are dropped and training returns GPIS_ERR_STATE.  wait_limit_ms = 0 keeps the default
- * (2 s); inject != 0 is a TEST hook that makes one workgroup of every cooperative cluster withhold a hand-over, so that
- * the error path can be exercised. */
+ * (2 s); inject is a TEST hook: bit 0 makes one workgroup of every cooperative cluster withhold a hand-over; bit 4 (16)
+ * makes the first workgroup of every prediction launch withhold one signal of its LDS ring (and shortens that kernel's
+ * bounded wait): its tile's results are NaN, the error word of the launch is raised and gpis_ongpis_eval / test() return
+ * GPIS_ERR_STATE -- so that the error paths can be exercised. */
 int   gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms);
+/* Device self-test (round 6): the factorisation kernels take their square roots and divisions through range-restricted sequences
+ * (csrc/tile_solve.h: the compiler's correctly rounded expansions without the operand scaling and classification the chains'
+ * operands never need).  Runs blocks * 256 * per_thread random operand pairs through them and through the compiler's sqrtf and `/`
+ * on the current device and returns the number of results whose bits differ: mismatches2[0] square roots, [1] divisions.
+ * mode 0: the documented operand ranges; mode 1: operands shaped like the factorisations'. */
+int   gpis_selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, int mode, unsigned long long* mismatches2);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 
 #ifdef __cplusplus

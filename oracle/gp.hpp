@@ -467,20 +467,24 @@ struct OnGPIS {
 
     // Reduction order (O3) of the sum of squares ||V||^2 (tiled mode).  Eigen evaluates it with packet-wise
     // interleaved partial sums (order unspecified); this restatement fixes the order in which a 32x32-tiled
-    // triangular product over W cooperating wavefronts meets the rows.  With nbx = ceil((K+1)/32) block rows
-    // (row K carries the mean, below), W = 1, 2, 4, 8 for nbx <= 4, 8, 16, more.  Block rows are dealt to the
-    // wavefronts from the LARGEST down, in groups of 4W, snake-wise (block row b costs b+1 tile products, the snake
-    // balances the wavefronts): the i-th largest row b = nbx-1-i has group g = i / 4W, slot t = (i % 4W) / W,
-    // position q = i % W and belongs to wavefront w = (t odd) ? W-1-q : q.  Inside a 32-row block the two lane
-    // halves h = 0, 1 own the rows (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  Chain (w, h) takes fmaf(v, v, .) over
-    // its rows in the order (g, t, r) ascending; then (w,0)+(w,1) are added and the W sums accumulated in ascending w.
+    // triangular product over W cooperating wavefronts meets the rows.  W = 1, 2, 4, 8 for nbx <= 4, 8, 16, more,
+    // nbx = ceil((K+1)/32) (the leading dimension of the stored inverse: row K of it carries alpha, the mean).  The
+    // nbv = ceil(K/32) block rows of V are dealt to the wavefronts from the LARGEST down, in groups of 4W, snake-wise
+    // (block row b costs b+1 tile products, the snake balances the wavefronts): the i-th largest row b = nbv-1-i has
+    // group g = i / 4W, slot t = (i % 4W) / W, position q = i % W and belongs to wavefront w = (t odd) ? W-1-q : q.
+    // (K not a multiple of 32: nbv = nbx, the mean row rides in the last block row.  K a multiple of 32: the mean row
+    // would be a block row of its own -- 31 zero rows multiplied for nothing; it is a chain on the vector ALU instead and
+    // only the nbv rows of V are dealt.  Round 6; until round 5 the deal ran over nbx rows in that case too.)
+    // Inside a 32-row block the two lane halves h = 0, 1 own the rows (r & 3) + 8 (r >> 2) + 4 h, r = 0..15.  Chain (w, h)
+    // takes fmaf(v, v, .) over its rows in the order (g, t, r) ascending; then (w,0)+(w,1) are added and the W sums
+    // accumulated in ascending w.
     static int chains_W(int nbx) { return nbx <= 4 ? 1 : (nbx <= 8 ? 2 : (nbx <= 16 ? 4 : 8)); }
     static float reduce_ss(int K, const float* v) {
-        const int nbx = (K + 1 + 31) / 32, W = chains_W(nbx), RG = 4 * W;
+        const int nbx = (K + 1 + 31) / 32, nbv = (K + 31) / 32, W = chains_W(nbx), RG = 4 * W;
         float P[8][2];
         for (int w = 0; w < 8; ++w) P[w][0] = P[w][1] = 0.f;
-        for (int i = 0; i < nbx; ++i) {            // i ascending = (g, t) ascending for every wavefront
-            const int b = nbx - 1 - i, ii = i % RG, t = ii / W, q = ii % W;
+        for (int i = 0; i < nbv; ++i) {            // i ascending = (g, t) ascending for every wavefront
+            const int b = nbv - 1 - i, ii = i % RG, t = ii / W, q = ii % W;
             const int w = (t & 1) ? W - 1 - q : q;
             for (int h = 0; h < 2; ++h)
                 for (int r = 0; r < 16; ++r) {

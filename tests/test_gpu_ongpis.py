@@ -252,6 +252,82 @@ def test_cooperative_wait_expiry_is_reported():
     assert np.array_equal(np.concatenate([out[:, :4], out[:, 4:8]], axis=1).view(np.uint32), ref.view(np.uint32))
 
 
+def test_query_on_a_training_point_reproduces_the_references_nan():
+    """kf2 divides by r, so a query that coincides with a gradient-bearing training point makes the
+    reference's cross-covariance NaN (covFnc.cpp:31-33, no guard) and with it the whole prediction of that query.  The
+    kernels reproduce it (the shared-reciprocal division of K4's generation included): NaN where the oracle has NaN, the same
+    bits everywhere else."""
+    import gpismap_amd
+    dim, scale = 3, 0.04
+    rng = np.random.default_rng(31)
+    n = 90
+    pos, grad, val, sx, sg = make_cluster(rng, dim, n, scale, frac_nograd=0.0)
+    st = gpismap_amd.OnGPIS(dim, scale)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    xq = (pos[rng.integers(0, n, 24)] + rng.normal(0, 0.3 * scale, (24, dim))).astype(np.float32)
+    xq[[3, 8, 17]] = pos[[5, 40, 77]]                # three queries ON training points
+    out = st.eval(xq, np.arange(24, dtype=np.int32), np.full(24, models[0], dtype=np.int32))
+    ref = oracle_lib.ongpis_predict(dim, scale, pos, grad, val, sx, sg, xq)
+    got = np.concatenate([out[:, :4], out[:, 4:8]], axis=1)
+    assert np.isnan(ref[[3, 8, 17]]).any(axis=1).all() and not np.isnan(ref[[0, 1, 2]]).any()
+    assert np.array_equal(np.isnan(got), np.isnan(ref))
+    ok = ~np.isnan(ref)
+    assert np.array_equal(got[ok].view(np.uint32), ref[ok].view(np.uint32))
+
+
+def test_ranged_sqrt_and_division_equal_the_ieee_ones():
+    """The pivot chains of the factorisations take sqrt and division through the compiler's own correctly rounded sequences
+    WITHOUT their operand scaling / classification (csrc/tile_solve.h).  On 2 x 33 million operand pairs -- the documented
+    ranges, and operands shaped like the factorisations' incl. zeros of both signs and unit quotients -- the device's IEEE
+    sqrtf and `/` give the same bits."""
+    import gpismap_amd
+    for mode in (0, 1):
+        bad_sqrt, bad_div = gpismap_amd.selftest_ranged_arith(seed=20261003 + mode, blocks=2048, per_thread=64, mode=mode)
+        assert (bad_sqrt, bad_div) == (0, 0), (mode, bad_sqrt, bad_div)
+
+
+def test_ring_wait_expiry_of_the_predictor_is_reported():
+    """K4 hands its B chunks over through LDS counters with BOUNDED waits.  A signal that never arrives (injected: the first
+    workgroup of every launch withholds one) must neither hang the queue nor produce plausible numbers: the wait expires,
+    the tile's results are NaN, the launch's error word makes the call fail with GPIS_ERR_STATE, every other tile is
+    untouched, and the next call is clean."""
+    import time
+    import gpismap_amd
+    dim, scale = 3, 0.04
+    rng = np.random.default_rng(4242)
+    sizes = [70, 300]                              # K ~ 240 (two wavefronts per workgroup) and K ~ 1000 (eight): two launches
+    clusters = [make_cluster(rng, dim, n, scale) for n in sizes]
+    pos = np.concatenate([c[0] for c in clusters]); grad = np.concatenate([c[1] for c in clusters])
+    val = np.concatenate([c[2] for c in clusters]); sx = np.concatenate([c[3] for c in clusters])
+    sg = np.concatenate([c[4] for c in clusters])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    st = gpismap_amd.OnGPIS(dim, scale)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), off, np.arange(off[-1], dtype=np.int32))
+    nq = 24 * 8                                    # 24 tiles per cluster
+    xq = np.concatenate([pos[off[i]:off[i + 1]][rng.integers(0, sizes[i], nq)] + rng.normal(0, 0.3 * scale, (nq, dim))
+                         for i in range(2)]).astype(np.float32)
+    jq = np.arange(2 * nq, dtype=np.int32)
+    jm = np.repeat(models, nq).astype(np.int32)
+    clean = st.eval(xq, jq, jm).copy()
+    assert np.isfinite(clean).all()
+    st.set_debug(inject=16)
+    t0 = time.time()
+    rc, out = st.eval(xq, jq, jm, return_status=True)
+    assert time.time() - t0 < 20.0                 # bounded
+    assert rc == -3                                # GPIS_ERR_STATE
+    bad = np.isnan(out[:, :4]).any(axis=1)
+    # the first workgroup of each of the two launches: one tile of 8 queries per cluster, all of its results NaN
+    for i in range(2):
+        b = bad[i * nq:(i + 1) * nq]
+        assert b.sum() == 8, b.sum()
+        rows = out[i * nq:(i + 1) * nq][b]
+        assert np.isnan(rows[:, :4]).all() and np.isnan(rows[:, 4:8]).all()
+    assert np.array_equal(out[~bad].view(np.uint32), clean[~bad].view(np.uint32))
+    st.set_debug(inject=0)
+    again = st.eval(xq, jq, jm)
+    assert np.array_equal(again.view(np.uint32), clean.view(np.uint32))
+
+
 def test_cluster_the_predictor_cannot_hold_is_refused_at_training():
     """K4 stages a cluster's row table and points in LDS; a cluster of very many value-only points fits the factorisation
     but not that staging.  It is refused when it is TRAINED (GPIS_ERR_LIMIT, nothing factorised) instead of making every

@@ -110,13 +110,13 @@ def test_reset_and_destroy_join_the_training_in_flight():
 
 def test_default_mode_and_cu_reserve(monkeypatch):
     """update() is pipelined by default and its training streams then leave CUs to the ObsGP batches of the next frame
-    (GPIS_PIPELINE_RESERVE_CUS, default 32); the synchronous mode gives the reserve back; the environment can turn the
+    (GPIS_PIPELINE_RESERVE_CUS, default 64); the synchronous mode gives the reserve back; the environment can turn the
     default off (the unchanged mex gateway has no other switch)."""
     monkeypatch.delenv("GPIS_PIPELINE_UPDATE", raising=False)
     monkeypatch.delenv("GPIS_PIPELINE_RESERVE_CUS", raising=False)
     gm = gpismap_amd.GPisMap3()
     s = gm.stats()
-    assert s["pipelined"] == 1 and s["train_cu_reserve"] == 32
+    assert s["pipelined"] == 1 and s["train_cu_reserve"] == 64
     gm.update(replay.synthetic_depth(0), replay.IDENTITY_POSE)
     gm.set_pipeline(False)                       # joins the training in flight, recreates the training streams unmasked
     s = gm.stats()

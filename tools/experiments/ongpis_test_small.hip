@@ -314,7 +314,7 @@ __global__ __launch_bounds__(64 * kSW, 2) void ongpis_eval_small_kernel(EvalArgs
 int ongpis_eval_small_launch(int ntiles, int maxN, int maxLd, const EvalArgs& args, hipStream_t s) {
     if (ntiles <= 0) return GPIS_OK;
     if (maxLd / 32 > kSNB) return GPIS_ERR_ARG;
-    const bool table = args.use_table && small_lds(maxN, maxLd, true) <= (size_t)160 * 1024;
+    const bool table = small_lds(maxN, maxLd, true) <= (size_t)160 * 1024;   // (its own exp table in LDS when it fits)
     const size_t lds = small_lds(maxN, maxLd, table);
     if (lds > 160 * 1024) return GPIS_ERR_LIMIT;
     if (ensure_dynamic_lds((const void*)ongpis_eval_small_kernel, 160 * 1024) != GPIS_OK) return GPIS_ERR_HIP;
