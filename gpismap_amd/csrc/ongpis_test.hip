@@ -37,6 +37,7 @@
 #include <type_traits>
 #include "ongpis.h"
 #include "tile_solve.h"
+#include "exp_tab.h"
 
 namespace gpis {
 
@@ -134,7 +135,8 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
     lds_cnt_t ring_cnt = (lds_cnt_t)(reinterpret_cast<int*>(s_xq + 16));    // [0..2] tiles generated per slot, [8..10] wavefronts done per slot (cumulative), [15] a wait expired
     if (tid < 16) ring_cnt[tid] = 0;
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
-    float* Bbuf = reinterpret_cast<float*>(s_x4 + N);                  // [NSLOT][CB][32*36]
+    f64x2* s_exp = reinterpret_cast<f64x2*>(s_x4 + N);                 // [64] 2^(j/64) as (hi, lo): exp_tab.h
+    float* Bbuf = reinterpret_cast<float*>(s_exp + 64);                // [NSLOT][CB][32*36]
 
     const float scale = mp->scale;
     const float a = (float)(sqrt(3.0) / (double)scale);
@@ -145,6 +147,7 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
         for (int i = tid; i < ld; i += 64 * W) s_ri[i] = g_ri[i];
         for (int i = tid; i < 4 * N; i += 64 * W) reinterpret_cast<float*>(s_x4)[i] = g_x4[i];
         if (tid < 16) s_xq[tid] = (tid < jcnt) ? A.xq[A.job_q[joff + tid]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < 64) s_exp[tid] = *reinterpret_cast<const f64x2*>(kExp64Tab[tid]);
         __syncthreads();
     }
     K4_STAMP();
@@ -183,8 +186,8 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
             if (row < K && q < jcnt) {
                 const float4 xq = s_xq[q];
                 float d[3] = {xp.x - xq.x, xp.y - xq.y, xp.z - xq.z};
-                float rr = (dim == 3) ? sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]) : sqrtf(d[0] * d[0] + d[1] * d[1]);
-                const double e = exp((double)(-a * rr));
+                float rr = sqrt_ranged((dim == 3) ? (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2] : d[0] * d[0] + d[1] * d[1]);   // (= sqrtf: squared distances are 0 or far above 2^-96)
+                const double e = exp_neg_tab(-a * rr, s_exp);
                 float v0, v1, v2, v3;
                 if (cr == 0) {
                     v0 = d_kf(rr, a, e); v1 = d_kf1(d[0], a, e); v2 = d_kf1(d[1], a, e); v3 = d_kf1(d[2], a, e);
@@ -426,7 +429,7 @@ static const int kClassW[ONGPIS_NCLASS] = {1, 2, 4, 4, kW3, kW3, kW3};
 constexpr int kWavesPerCU = 4 * kMinW;   // resident wavefronts per CU the register budget of the kernels admits
 
 static size_t eval_lds_fixed(int W, int maxN, int maxLd) {
-    return sizeof(float) * (W * 32 + 32) + 16 * sizeof(float4) + 32 * sizeof(int) + sizeof(int) * (size_t)maxLd + 16 * (size_t)maxN;
+    return sizeof(float) * (W * 32 + 32) + 16 * sizeof(float4) + 32 * sizeof(int) + sizeof(int) * (size_t)maxLd + 16 * (size_t)maxN + 64 * 16;
 }
 
 int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalArgs& args_in, hipStream_t s) {
