@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--frames", type=int, default=5, help="synthetic depth frames fused before testing (SURVEY 8d: F = 5)")
     ap.add_argument("--grid", type=int, default=256, help="query grid is grid^3 points")
     ap.add_argument("--update-repeats", type=int, default=5, help="fuse the frame sequence this many times (fresh maps); headline = median of frames 2..F of the MEDIAN repeat (the minimum over the repeats is a side field)")
-    ap.add_argument("--train", default="replicated", choices=["replicated", "sharded"], help="multi-rank update(): every rank trains everything, or its K^3-balanced share + all-gather of the models")
+    ap.add_argument("--train", default="replicated", choices=["replicated", "sharded", "lead"], help="multi-rank update(): every rank trains everything, or its K^3-balanced share + all-gather of the models; lead = sharded with the host logic run once on rank 0 (frame records broadcast, the other ranks apply them)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the measured path) or gloo (rehearsal of the multi-rank logic on fewer GPUs: transfers staged through host memory)")
     ap.add_argument("--block", type=int, default=65536, help="queries per block of the block-cyclic cut")
     ap.add_argument("--cpu-sample", type=int, default=64, help="CPU baseline runs on a sample^3 subgrid (0 = skip); SURVEY 8(d): 64^3")
@@ -100,7 +100,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    sharded = world > 1 and args.train == "sharded"
+    sharded = world > 1 and args.train in ("sharded", "lead")
+    lead_mode = world > 1 and args.train == "lead"       # host logic of update() once, on rank 0 (gpismap_amd.sharding.update_lead_worker)
+    host_replays = frame_record_bytes = 0
 
     # ---- set-up (untimed): fuse the synthetic frames; time update() per frame ----
     # The host side of update() (single-threaded tree replay) varies by +-30 % from box to box and run to run, so the
@@ -125,14 +127,20 @@ def main():
         gm.set_lazy_inverse(not eager)
         if sharded:
             gm.set_shard(rank, world)
+        if lead_mode and rank == 0:
+            gm.set_frame_export(True)
         upd_ms, phases, k3 = [], [], []
+        host_replays = frame_record_bytes = 0
         exch_bytes = exch_padded = exch_records = 0
         for f in range(args.frames):
             depth = replay.synthetic_depth(f)
             if world > 1:
                 dist.barrier()
             t0 = time.perf_counter()
-            gm.update(depth, replay.IDENTITY_POSE)
+            if lead_mode:
+                frame_record_bytes += sharding.update_lead_worker(gm, depth, replay.IDENTITY_POSE, world, rank, dev, host_staged)
+            else:
+                gm.update(depth, replay.IDENTITY_POSE)
             if sharded:
                 te = time.perf_counter()
                 _, nb, npad, nrec = sharding.exchange_models(gm, world, rank, dev, host_staged)
@@ -140,6 +148,7 @@ def main():
                 exch_ms.append((time.perf_counter() - te) * 1e3)
             upd_ms.append((time.perf_counter() - t0) * 1e3)
             s = gm.stats()
+            host_replays += int(s["host_replays"])
             phases.append([s["upd_preproc_ms"], s["upd_obsgp_train_ms"], s["upd_reeval_ms"], s["upd_eval_ms"], s["upd_gps_ms"]])
             k3.append(dict(ms=s["last_train_ms"], flops=s["last_train_flops"], bytes=s["last_train_bytes"],
                            clusters=int(s["last_train_jobs"]), maxK=int(s["last_train_maxK"])))
@@ -231,12 +240,12 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_staged else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        ev = torch.tensor([evals_rank, k4_ms / max(1, args.steps)], dtype=torch.float64, device="cpu" if host_staged else dev)
+        ev = torch.tensor([evals_rank, k4_ms / max(1, args.steps), float(host_replays)], dtype=torch.float64, device="cpu" if host_staged else dev)
         evs = [torch.zeros_like(ev) for _ in range(world)]
         dist.all_gather(evs, ev)
         per_rank = [[float(v) for v in e.cpu()] for e in evs]
     else:
-        per_rank = [[evals_rank, k4_ms / max(1, args.steps)]]
+        per_rank = [[evals_rank, k4_ms / max(1, args.steps), float(host_replays)]]
 
     # ---- --verify (any backend, outside the timed region): per-rank phase times of one extra step, and the assembled map
     # against a single-rank pass of rank 0 over a 64^3 sub-grid, bit for bit
@@ -403,14 +412,15 @@ def main():
         tflops = (flops / 1e12) / (k4_ms / 1e3) if k4_ms > 0 else None
         # HBM bytes per K4 launch: rocprofv3 PMC passes of this command (tools/measure_traffic.sh), valid only for the
         # kernel source they were measured on
-        traffic = None
-        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_k4_traffic.json" % r) for r in ("r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
+        traffic = traffic_step = None
+        tpath = next((q for q in (os.path.join(ROOT, "profiles", "%s_k4_traffic.json" % r) for r in ("r06", "r05", "r04", "r03", "r02")) if os.path.exists(q)), "")
         if tpath:
             with open(tpath) as fh:
                 tj = json.load(fh)
             if (tj.get("ongpis_test_sha") == file_sha(os.path.join(ROOT, "gpismap_amd", "csrc", "ongpis_test.hip"))
                     and tj.get("grid") == args.grid and tj.get("frames") == args.frames):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_step = tj.get("hbm_bytes_per_pass")
         med = med_tail
         ph = np.array(phases)
         ksel = k3[1:] if len(k3) > 1 else k3
@@ -464,11 +474,21 @@ def main():
             "update_phases_ms": dict(zip(["preproc", "obsgp_train", "reeval_points", "new_points", "update_gps"],
                                          [float(v) for v in (np.median(ph[1:], axis=0) if len(ph) > 1 else ph[0])])),
             "gp_evals_per_point": sum(p[0] for p in per_rank) / n_total,
-            "per_rank": dict({"gp_evals": [p[0] for p in per_rank], "k4_ms_per_step": [p[1] for p in per_rank]}, **(detail or {})),
+            # host_replays: executions of update()'s host logic per rank over the last fusion (F per rank when every rank replays; --train lead: F on rank 0, 0 elsewhere)
+            "per_rank": dict({"gp_evals": [p[0] for p in per_rank], "k4_ms_per_step": [p[1] for p in per_rank], "host_replays": [int(p[2]) for p in per_rank]}, **(detail or {})),
+            "frame_record_bytes_per_frame": (frame_record_bytes / max(1, args.frames)) if lead_mode else 0,
             "roofline": {"bound": "mfma", "achieved": tflops, "peak": 157.3, "unit": "TFLOP/s",
                          "frac": (tflops / 157.3) if tflops else None, "traffic": traffic,
-                         # HBM-side bytes per launch over the algorithmic bytes per launch (44 B per query + 32 B per evaluated (query, cluster) pair + the models once)
+                         # `traffic` = HBM-side bytes per K4 LAUNCH (the unit the contract names; a step is k4_launches_per_step launches),
+                         # `traffic_per_step` the same per 256^3 pass -- the unit of everything else in this line
+                         "traffic_unit": "HBM-side bytes per K4 launch (rocprofv3 PMC passes, FETCH_SIZE x 2 + WRITE_SIZE); traffic_per_step = per test() pass",
+                         "traffic_per_step": traffic_step,
+                         # over the algorithmic bytes of the same unit.  bench's denominator: 44 B per query + 32 B per evaluated (query, cluster)
+                         # pair + the models once; SURVEY 8(d)'s: 44 B per query + the models once
                          "traffic_ratio": (traffic / ((44.0 * n_loc + 32.0 * evals / max(1, args.steps) + st0["model_bytes"]) / max(1.0, launches / args.steps))) if traffic else None,
+                         "traffic_ratio_survey_8d": (traffic_step / (44.0 * n_loc + st0["model_bytes"])) if traffic_step else None,
+                         "algorithmic_bytes_per_step": 44.0 * n_loc + 32.0 * evals / max(1, args.steps) + st0["model_bytes"],
+                         "algorithmic_bytes_per_step_survey_8d": 44.0 * n_loc + st0["model_bytes"],
                          "kernel": "ongpis_eval_kernel (K4)", "k4_ms_per_step": k4_ms / args.steps,
                          "k4_launches_per_step": launches / args.steps,
                          "algorithmic_flops_per_step": flops / args.steps,

@@ -52,6 +52,12 @@ def lib():
     L.gpis3_shard_pack.argtypes = [vp, vp, vp]
     L.gpis3_shard_unpack.argtypes = [vp, C.c_int, vp, vp]
     L.gpis3_shard_finish.argtypes = [vp]
+    if hasattr(L, "gpis3_apply_frame"):
+        L.gpis3_set_frame_export.argtypes = [vp, C.c_int]
+        L.gpis3_frame_record.argtypes = [vp, vp, C.c_longlong]
+        L.gpis3_frame_record.restype = C.c_longlong
+        L.gpis3_train_deferred.argtypes = [vp]
+        L.gpis3_apply_frame.argtypes = [vp, vp, C.c_longlong]
     L.gpis_ongpis_packed_bytes.argtypes = [vp, ip, C.c_int]; L.gpis_ongpis_packed_bytes.restype = C.c_longlong
     L.gpis_ongpis_pack.argtypes = [vp, ip, C.c_int, vp, C.c_longlong, vp]
     L.gpis_ongpis_unpack.argtypes = [vp, vp, C.c_int, C.c_longlong, ip, vp]
@@ -259,6 +265,28 @@ class GPisMap3:
 
     def shard_finish(self):
         _check(self.L.gpis3_shard_finish(self.h), "gpis3_shard_finish")
+
+    # ---- one process per GPU, host logic once (gpis3_set_frame_export ...; gpismap_amd.sharding.update_lead_worker) ----
+    def set_frame_export(self, on=True):
+        _check(self.L.gpis3_set_frame_export(self.h, 1 if on else 0), "gpis3_set_frame_export")
+
+    def frame_record(self):
+        """The record of the last update() on the lead (numpy uint8)."""
+        n = int(self.L.gpis3_frame_record(self.h, None, 0))
+        if n < 0:
+            raise GpisError("gpis3_frame_record failed (%d)" % n)
+        buf = np.empty(max(n, 1), dtype=np.uint8)
+        m = int(self.L.gpis3_frame_record(self.h, buf.ctypes.data_as(C.c_void_p), n))
+        if m != n:
+            raise GpisError("gpis3_frame_record failed (%d)" % m)
+        return buf[:n]
+
+    def train_deferred(self):
+        _check(self.L.gpis3_train_deferred(self.h), "gpis3_train_deferred")
+
+    def apply_frame(self, record):
+        record = np.ascontiguousarray(record, dtype=np.uint8)
+        _check(self.L.gpis3_apply_frame(self.h, record.ctypes.data_as(C.c_void_p), int(record.size)), "gpis3_apply_frame")
 
     def num_points(self):
         return self.L.gpis3_num_points(self.h)

@@ -35,6 +35,10 @@ long long gpis3_impl_shard_bytes(GPisMap3* m, int owner);
 int gpis3_impl_shard_pack(GPisMap3* m, void* d_buf, void* stream);
 int gpis3_impl_shard_unpack(GPisMap3* m, int owner, const void* d_buf, void* stream);
 int gpis3_impl_shard_finish(GPisMap3* m);
+int gpis3_impl_set_frame_export(GPisMap3* g, int on);
+long long gpis3_impl_frame_record(GPisMap3* g, void* buf, long long cap);
+int gpis3_impl_train_deferred(GPisMap3* g);
+int gpis3_impl_apply_frame(GPisMap3* g, const void* buf, long long bytes);
 int gpis2_impl_device(GPisMap* m);
 
 namespace gpis { int selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, int mode, unsigned long long* mismatches); }
@@ -124,6 +128,10 @@ int gpis3_shard_unpack(void* m, int owner, const void* d_buf, void* stream) {
     return gpis3_impl_shard_unpack((GPisMap3*)m, owner, d_buf, stream);
 }
 int gpis3_shard_finish(void* m) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_shard_finish((GPisMap3*)m); }
+int gpis3_set_frame_export(void* m, int on) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_set_frame_export((GPisMap3*)m, on); }
+long long gpis3_frame_record(void* m, void* buf, long long cap) { if (!m || cap < 0) return GPIS_ERR_ARG; return gpis3_impl_frame_record((GPisMap3*)m, buf, cap); }
+int gpis3_train_deferred(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis3_impl_train_deferred((GPisMap3*)m); } catch (...) { return GPIS_ERR_STATE; } }
+int gpis3_apply_frame(void* m, const void* buf, long long bytes) { if (!m) return GPIS_ERR_ARG; return gpis3_impl_apply_frame((GPisMap3*)m, buf, bytes); }
 int gpis3_num_points(void* m) {
     if (!m) return GPIS_ERR_ARG;
     std::vector<float> p; ((GPisMap3*)m)->getAllPoints(p); return (int)(p.size() / 3);

@@ -148,6 +148,25 @@ struct GPisMap3::Impl {
     std::vector<ShardJob> shard_jobs;
     bool table_pending = false;   // update() trained the local share only: the cluster table waits for the exchange
     void build_cluster_table();
+    // One process per GPU with the host logic run ONCE (round 6; gpis3_set_frame_export / gpis3_frame_record / gpis3_apply_frame).
+    // The LEAD process runs update() as ever, writes down what the frame decided -- the slot operations in order, the point mirror,
+    // the cell lists and cluster descriptors of the K6 pass, the training jobs with their owners, the cluster table's entries --
+    // and puts the training of its own share off until gpis3_train_deferred(), so that the record can travel first.  A WORKER
+    // process never replays the frame: gpis3_apply_frame() mirrors the slot operations on its store (the ids must come out as
+    // recorded), uploads the mirror, runs K6 on its own device, trains its share and keeps the table entries for the exchange
+    // that follows (gpis3_shard_pack / _unpack / _finish, unchanged).  A worker holds no tree: getAllPoints is the lead's business.
+    bool export_frames = false;
+    std::vector<char> frame_rec;
+    std::vector<int> slot_ops;                   // this frame's slot operations in order: ~slot released, slot >= 0 taken
+    std::vector<TrainJob> deferred_jobs;         // the lead's own share, waiting for gpis3_train_deferred()
+    std::vector<int> deferred_ids;
+    bool deferred_train = false, deferred_dev = true;
+    bool remote_index = false;                   // worker process: the cluster table is built from the lead's entries
+    std::vector<ClusterEntry> frame_ent;
+    std::vector<AncestorEntry> frame_anc;
+    void collect_cluster_entries(std::vector<ClusterEntry>& ent, std::vector<AncestorEntry>& anc) const;
+    int train_deferred();
+    int apply_frame(const char* buf, size_t bytes);
 
     // ---- several devices behind ONE map object (GPIS_DEVICES=0,1,... or gpis3_create_multi): this instance is rank 0,
     // `peers` are ranks 1..n-1, each a complete map on its own device.  update(): every rank runs the same deterministic
@@ -175,6 +194,7 @@ struct GPisMap3::Impl {
     }
     int new_slot_all() {                         // the same slot id on every rank (the stores see the same sequence of operations)
         const int s = store.new_slot();
+        if (export_frames) slot_ops.push_back(s);
         for (GPisMap3* q : peers) {
             DeviceScope ds(q->impl()->device);
             if (q->impl()->store.new_slot() != s && !upd_rc) { upd_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] model slots of the devices diverged\n"); }
@@ -818,10 +838,62 @@ void GPisMap3::Impl::evalPoints() {  // GPisMap3.cpp:580-696
 }
 
 // -------------------------------------------------------------------- updateGPs ----
+// ---- frame records (one process per GPU, host logic once: see Impl::export_frames) -------------------------------------------
+namespace {
+constexpr unsigned kFrameMagic = 0x46335047u;      // "GP3F"
+struct FrameHeader {
+    unsigned magic, version;
+    int rc, device_gather, total, nothing;       // nothing = 1: the lead's update() returned before it touched the map (no valid pixel ...)
+    unsigned long long np, n_slot_ops, n_cell_pts, n_cr, n_desc, n_counts, n_jobs, n_ids, n_ent, n_anc;
+};
+struct FrameWriter {
+    std::vector<char>& b;
+    template <class T> void put(const T* p, size_t n) { const size_t o = b.size(); b.resize(o + ((sizeof(T) * n + 7) & ~(size_t)7)); if (n) std::memcpy(b.data() + o, p, sizeof(T) * n); }
+};
+struct FrameReader {
+    const char* p; size_t left; bool ok = true;
+    template <class T> const T* take(size_t n) {
+        const size_t need = (sizeof(T) * n + 7) & ~(size_t)7;
+        if (!ok || need > left) { ok = false; return nullptr; }
+        const T* r = reinterpret_cast<const T*>(p); p += need; left -= need; return r;
+    }
+};
+}  // namespace
+
 void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     UpdLap ulap;
     shard_jobs.clear();
     table_pending = false;
+    deferred_train = false; deferred_jobs.clear(); deferred_ids.clear();
+    // the frame's record for worker processes (export_frames): written once the frame's decisions are complete
+    auto write_record = [&](int rc_, size_t np_, const std::vector<int>* cell_pts, const std::vector<int>* cr_, const std::vector<int>* desc_,
+                            int total_, const std::vector<int>* counts_, const std::vector<TrainJob>* jobs_, const std::vector<int>* ids_) {
+        static const std::vector<int> none;
+        static const std::vector<TrainJob> nojobs;
+        std::vector<ClusterEntry> ent; std::vector<AncestorEntry> anc;
+        collect_cluster_entries(ent, anc);
+        FrameHeader h;
+        std::memset(&h, 0, sizeof(h));
+        h.magic = kFrameMagic; h.version = 1; h.rc = rc_; h.device_gather = device_gather ? 1 : 0; h.total = total_;
+        const std::vector<int>& cp = cell_pts ? *cell_pts : none; const std::vector<int>& crr = cr_ ? *cr_ : none;
+        const std::vector<int>& ds_ = desc_ ? *desc_ : none; const std::vector<int>& cn = counts_ ? *counts_ : none;
+        const std::vector<TrainJob>& jb = jobs_ ? *jobs_ : nojobs; const std::vector<int>& idv = ids_ ? *ids_ : none;
+        h.np = np_; h.n_slot_ops = slot_ops.size(); h.n_cell_pts = cp.size(); h.n_cr = crr.size(); h.n_desc = ds_.size();
+        h.n_counts = cn.size(); h.n_jobs = jb.size(); h.n_ids = idv.size(); h.n_ent = ent.size(); h.n_anc = anc.size();
+        frame_rec.clear();
+        FrameWriter w{frame_rec};
+        w.put(&h, 1);
+        w.put(slot_ops.data(), slot_ops.size());
+        w.put(mirror_soa.data(), np_ ? 9 * np_ : 0);
+        w.put(cp.data(), cp.size()); w.put(crr.data(), crr.size()); w.put(ds_.data(), ds_.size()); w.put(cn.data(), cn.size());
+        w.put(jb.data(), jb.size());
+        std::vector<int> owners(jb.size(), 0);
+        for (size_t j = 0; j < jb.size() && j < shard_jobs.size(); ++j) owners[j] = shard_jobs[j].owner;
+        w.put(owners.data(), owners.size());
+        w.put(idv.data(), idv.size());
+        w.put(ent.data(), ent.size()); w.put(anc.data(), anc.size());
+    };
+    bool record_written = false;
     T3::Set updateSet(activeSet);
     std::vector<int> qs;
     for (int a : activeSet) {
@@ -835,7 +907,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
     auto join_previous = [&]() {
         finish_training();
         ulap("updateGPs: join");
-        for (int m : tree.released_models) each_store([&](OnGPISStore& st) { st.release_slot(m); });
+        for (int m : tree.released_models) { each_store([&](OnGPISStore& st) { st.release_slot(m); }); if (export_frames) slot_ops.push_back(~m); }
         tree.released_models.clear();
     };
     if (updateSet.empty()) join_previous();
@@ -995,6 +1067,11 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                     if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
                     for (auto& t : th) t.join();
                     for (size_t r = 1; r < wrc.size(); ++r) if (wrc[r] != GPIS_OK && rc == GPIS_OK) rc = wrc[r];
+                } else if (export_frames) {
+                    // one process per GPU, this is the lead: the record first, the own share when the caller says so (gpis3_train_deferred)
+                    write_record(rc, np_mirror, &cell_lists.pts, &cr, &desc, total, &counts, &jobs, &ids);
+                    record_written = true;
+                    if (rc == GPIS_OK && !mine.empty()) { deferred_jobs = mine; deferred_ids = ids; deferred_dev = device_gather; deferred_train = true; }
                 } else if (rc == GPIS_OK && !mine.empty()) rc = train(mine);
                 table_pending = true;
             } else if (rc == GPIS_OK) rc = train(jobs);
@@ -1004,12 +1081,86 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         }
     }
     activeSet.clear();
+    if (export_frames && !record_written) write_record(upd_rc, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr);   // (a frame without training: slot operations and the table only)
+    slot_ops.clear();
     if (!table_pending) {
         build_cluster_table();
         // (nothing was trained, but cells may have come or gone: the workers' tables follow the lead's index too)
         for (GPisMap3* q : peers) { Impl& w = *q->impl(); DeviceScope ds(w.device); w.has_tree = true; w.build_cluster_table(); if (w.upd_rc && !upd_rc) upd_rc = w.upd_rc; }
     }
     ulap("updateGPs: cluster table");
+}
+
+// The lead process' own share of a frame whose record was exported (gpis3_train_deferred): what update() would have done in place.
+int GPisMap3::Impl::train_deferred() {
+    if (!deferred_train) return GPIS_OK;
+    deferred_train = false;
+    int rc = deferred_dev ? store.train_batch_dev(deferred_jobs, train_stream) : store.train_batch(deferred_jobs, deferred_ids, train_stream);
+    deferred_jobs.clear(); deferred_ids.clear();
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
+    return rc;
+}
+
+// A worker process' frame: the lead's record instead of a replay (Impl::export_frames).  Everything is checked before it is
+// used -- a record that does not fit this store (another slot sequence, counts that the device pass does not reproduce) is
+// refused with GPIS_ERR_STATE and leaves the map's models as they were.
+int GPisMap3::Impl::apply_frame(const char* buf, size_t bytes) {
+    FrameReader rd{buf, bytes};
+    const FrameHeader* hp = rd.take<FrameHeader>(1);
+    if (!hp || hp->magic != kFrameMagic || hp->version != 1) return GPIS_ERR_ARG;
+    const FrameHeader h = *hp;
+    const int* ops = rd.take<int>((size_t)h.n_slot_ops);
+    const float* soa = rd.take<float>(h.np ? (size_t)(9 * h.np) : 0);
+    const int* cell_pts = rd.take<int>((size_t)h.n_cell_pts);
+    const int* cr = rd.take<int>((size_t)h.n_cr);
+    const int* desc = rd.take<int>((size_t)h.n_desc);
+    const int* counts = rd.take<int>((size_t)h.n_counts);
+    const TrainJob* jobs = rd.take<TrainJob>((size_t)h.n_jobs);
+    const int* owners = rd.take<int>((size_t)h.n_jobs);
+    const int* ids = rd.take<int>((size_t)h.n_ids);
+    const ClusterEntry* ent = rd.take<ClusterEntry>((size_t)h.n_ent);
+    const AncestorEntry* anc = rd.take<AncestorEntry>((size_t)h.n_anc);
+    if (!rd.ok || h.n_desc % 8 != 0 || h.n_counts != h.n_desc / 4 || h.n_cr % 2 != 0) return GPIS_ERR_ARG;
+    stat_host_replays = 0;
+    if (h.nothing) { shard_jobs.clear(); table_pending = false; upd_rc = 0; return GPIS_OK; }
+    stat_deferred_inverses = 0;
+    upd_rc = 0;
+    shard_jobs.clear();
+    table_pending = false;
+    (void)finish_training();
+    // the slot operations, in the lead's order: this store must hand out the ids the lead's did
+    for (size_t i = 0; i < h.n_slot_ops; ++i) {
+        if (ops[i] < 0) store.release_slot(~ops[i]);
+        else if (store.new_slot() != ops[i]) { fprintf(stderr, "[gpismap_amd] apply_frame: model slots diverged from the lead's\n"); upd_rc = GPIS_ERR_STATE; return GPIS_ERR_STATE; }
+    }
+    remote_index = true; has_tree = true;
+    frame_ent.assign(ent, ent + h.n_ent); frame_anc.assign(anc, anc + h.n_anc);
+    int rc = h.rc;
+    std::vector<TrainJob> mine;
+    for (size_t j = 0; j < h.n_jobs; ++j) {
+        if (owners[j] < 0 || owners[j] >= shard_world) return GPIS_ERR_ARG;
+        shard_jobs.push_back({jobs[j].model, jobs[j].n, jobs[j].ng, owners[j]});
+        if (owners[j] == shard_rank) mine.push_back(jobs[j]);
+    }
+    if (h.n_jobs > 0) {
+        if (rc == GPIS_OK) rc = store.upload_points(soa, (int)h.np, train_stream);
+        const int ncl = (int)(h.n_desc / 8);
+        if (rc == GPIS_OK && h.device_gather && ncl > 0) {
+            std::vector<int> wcounts((size_t)h.n_counts, 0);
+            rc = store.gather_ranges(cell_pts, (int)h.n_cell_pts, cr, (int)(h.n_cr / 2), desc, ncl, h.total, wcounts.data(), train_stream);
+            if (rc == GPIS_OK && std::memcmp(wcounts.data(), counts, sizeof(int) * wcounts.size()) != 0) rc = GPIS_ERR_STATE;   // (this device's K6 pass must reproduce the lead's)
+        }
+        if (rc == GPIS_OK && !mine.empty()) {
+            store.defer_finish = false;
+            if (h.device_gather) rc = store.train_batch_dev(mine, train_stream);
+            else { std::vector<int> idv(ids, ids + h.n_ids); rc = store.train_batch(mine, idv, train_stream); }
+        }
+        stat_clusters_trained += (long)h.n_jobs;
+        table_pending = true;
+    }
+    if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] apply_frame: training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
+    if (!table_pending) build_cluster_table();
+    return upd_rc;
 }
 
 int GPisMap3::Impl::finish_training() {
@@ -1023,16 +1174,15 @@ int GPisMap3::Impl::finish_training() {
     return rc;
 }
 
-void GPisMap3::Impl::build_cluster_table() {
-    table_pending = false;
+void GPisMap3::Impl::collect_cluster_entries(std::vector<ClusterEntry>& ent, std::vector<AncestorEntry>& anc) const {
     const T3& tree = lead ? lead->tree : this->tree;    // (a device worker answers test() from the lead's index; its model slots are the lead's)
-
+    ent.clear(); anc.clear();
+    if (!(lead ? lead->has_tree : has_tree)) return;
     // cluster table for test(): every non-empty cluster cell in traversal order
     std::vector<int> cl;
     tree.all_clusters(cl);
-    std::vector<ClusterEntry> ent(cl.size());
+    ent.resize(cl.size());
     // ancestor chains (up to the root the map holds), shared between sibling cells
-    std::vector<AncestorEntry> anc;
     std::unordered_map<int, int> anc_of;
     std::function<int(int)> anc_index = [&](int node) -> int {
         if (node < 0) return -1;
@@ -1050,14 +1200,23 @@ void GPisMap3::Impl::build_cluster_table() {
     for (size_t i = 0; i < cl.size(); ++i) {
         const T3::TNode& t = tree.nodes[cl[i]];
         for (int d = 0; d < 3; ++d) { ent[i].c[d] = t.c[d]; ent[i].lo[d] = t.lo[d]; ent[i].hi[d] = t.hi[d]; }
-        // a cell whose training failed (allocation) has a live slot without a factor: no GP for test() (prior only)
-        { const ClusterModel* mm = store.model(t.model); ent[i].model = (mm && mm->base) ? t.model : -1; }
+        ent[i].model = t.model;          // (the slot; build_cluster_table keeps it only where this rank's store holds a trained model)
         ent[i].parent = anc_index(t.par);
     }
+}
+
+void GPisMap3::Impl::build_cluster_table() {
+    table_pending = false;
+    std::vector<ClusterEntry> ent;
+    std::vector<AncestorEntry> anc;
+    if (remote_index) { ent = frame_ent; anc = frame_anc; }      // (worker process: the lead's entries of the last frame record)
+    else collect_cluster_entries(ent, anc);
     stat_model_bytes = 0;
-    for (size_t i = 0; i < cl.size(); ++i) {
-        const ClusterModel* mm = store.model(tree.nodes[cl[i]].model);
+    for (ClusterEntry& e : ent) {
+        // a cell whose training failed (allocation) has a live slot without a factor: no GP for test() (prior only)
+        const ClusterModel* mm = store.model(e.model);
         if (mm && mm->base) stat_model_bytes += 4.0 * (3.0 * mm->N + mm->K + 0.5 * (double)mm->K * (mm->K + 1));
+        else e.model = -1;
     }
     int rc = mq.set_clusters(ent, anc, 2.0 * (double)kCleng, stream);
     if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] cluster table upload failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
@@ -1240,6 +1399,15 @@ void GPisMap3::update_one(float* dataz, int N, std::vector<float>& pose) try {
     m.stat_deferred_inverses = 0;
     m.shard_jobs.clear();       // an update that returns early (no valid pixel, failed regression) must not leave the
     m.table_pending = false;    // previous frame's job list to a later exchange
+    if (m.remote_index) { m.upd_rc = GPIS_ERR_STATE; fprintf(stderr, "[gpismap_amd] GPisMap3::update: this map applies the lead's frame records (gpis3_apply_frame)\n"); return; }
+    if (m.deferred_train) (void)m.train_deferred();      // (the caller never asked for the previous frame's own share: train it now)
+    if (m.export_frames) {      // (an update that returns early still leaves a record: "nothing happened")
+        FrameHeader h;
+        std::memset(&h, 0, sizeof(h));
+        h.magic = kFrameMagic; h.version = 1; h.nothing = 1;
+        m.frame_rec.assign((const char*)&h, (const char*)&h + sizeof(h));
+        m.slot_ops.clear();
+    }
     if (!m.ok) { m.upd_rc = GPIS_ERR_HIP; fprintf(stderr, "[gpismap_amd] GPisMap3::update: HIP device unavailable\n"); return; }
     m.tree.recycle();
     auto t0 = std::chrono::steady_clock::now();
@@ -1788,6 +1956,33 @@ int gpis3_impl_shard_finish(GPisMap3* g) {
     return m.upd_rc;
 }
 int gpis3_impl_update_fail(GPisMap3* g) { return g->impl()->upd_rc; }
+// host logic once across processes (Impl::export_frames)
+int gpis3_impl_set_frame_export(GPisMap3* g, int on) {
+    GPisMap3::Impl& m = *g->impl();
+    if (!m.peers.empty() || m.lead) return GPIS_ERR_STATE;      // (several devices behind one map share the lead's memory: nothing to export)
+    m.export_frames = on != 0;
+    if (!m.export_frames) { m.frame_rec.clear(); m.slot_ops.clear(); }
+    return GPIS_OK;
+}
+long long gpis3_impl_frame_record(GPisMap3* g, void* buf, long long cap) {     // bytes of the last update()'s record; copied when buf holds them
+    GPisMap3::Impl& m = *g->impl();
+    if (!m.export_frames) return GPIS_ERR_STATE;
+    const long long n = (long long)m.frame_rec.size();
+    if (buf && cap >= n && n > 0) std::memcpy(buf, m.frame_rec.data(), (size_t)n);
+    return n;
+}
+int gpis3_impl_train_deferred(GPisMap3* g) {
+    GPisMap3::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    return m.train_deferred();
+}
+int gpis3_impl_apply_frame(GPisMap3* g, const void* buf, long long bytes) {
+    GPisMap3::Impl& m = *g->impl();
+    if (!buf || bytes < (long long)sizeof(FrameHeader)) return GPIS_ERR_ARG;
+    if (!m.ok || !m.peers.empty() || m.lead || m.export_frames || (m.has_tree && !m.remote_index)) return GPIS_ERR_STATE;   // (a map that replays frames itself is not a worker)
+    DeviceScope ds(m.device);
+    try { return m.apply_frame((const char*)buf, (size_t)bytes); } catch (...) { m.upd_rc = GPIS_ERR_STATE; return GPIS_ERR_STATE; }
+}
 void gpis3_impl_stats(GPisMap3* g, double* out, int n) {
     GPisMap3::Impl& m = *g->impl();
     DeviceScope ds(m.device);

@@ -14,6 +14,8 @@
 // are the fixed chains of dev_common.h, so results are bit-identical to the
 // unblocked CPU order (given equal exp()).
 #include "obsgp.h"
+#include "tile_solve.h"
+#include "exp_tab.h"
 
 namespace gpis {
 
@@ -145,7 +147,7 @@ __device__ __forceinline__ int obsgp_lookup1(const ObsGPView& v, float q0) {
 // go to val[qi] / var[qi].  sbuf is used twice: first the k* vectors of the lanes (sbuf[i * 64 + lane]), then -- once those are in
 // registers -- the factor, column-major (sbuf[j * 64 + i] = L(i, j)).  All 64 lanes call it (barriers inside).
 __device__ __forceinline__ void obsgp_query_group(const ObsGPView& v, int gt, bool mine, float q0, float q1, int qi, int lane,
-                                                  float* __restrict__ val, float* __restrict__ var, float* sbuf, float* sx, float* sa) {
+                                                  float* __restrict__ val, float* __restrict__ var, float* sbuf, float* sx, float* sa, const f64x2* sexp) {
     const float a = 1 / OU_SCALE;
     {
         const int n = v.tn[gt];
@@ -156,7 +158,12 @@ __device__ __forceinline__ void obsgp_query_group(const ObsGPView& v, int gt, bo
         // cross-covariances in a rolled loop (the exp sequence stays compact), parked in LDS, then into registers
         if (mine) {
 #pragma unroll 1
-            for (int i = 0; i < n; ++i) sbuf[i * 64 + lane] = d_ou_k(d_dist2(sx[2 * i], sx[2 * i + 1], q0, q1), a);
+            for (int i = 0; i < n; ++i) {
+                // d_ou_k(d_dist2(...)) with the table-driven exponential (exp_tab.h) and the range-restricted square root (tile_solve.h):
+                // the exponentials were more than half of this kernel's instruction issue
+                const float tx_ = sx[2 * i] - q0, ty_ = sx[2 * i + 1] - q1;
+                sbuf[i * 64 + lane] = (float)exp_neg_tab(-a * sqrt_ranged(tx_ * tx_ + ty_ * ty_), sexp);
+            }
         }
         float k[64];
 #pragma unroll
@@ -220,7 +227,9 @@ __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const floa
     __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
     __shared__ __attribute__((aligned(16))) float sx[128];
     __shared__ __attribute__((aligned(16))) float sa[64];
+    __shared__ f64x2 sexp[64];
     const int lane = threadIdx.x;
+    sexp[lane] = *reinterpret_cast<const f64x2*>(kExp64Tab[lane]);      // (read behind the first barrier of obsgp_query_group)
     const int slot = blockIdx.x * 64 + lane;
     const bool have = PERM ? (slot < *ngq) : (slot < nq);
     const int qi = PERM ? (have ? perm[slot] : 0) : slot;
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(64) void obsgp_query_kernel(ObsGPView v, const floa
         const int leader = __ffsll((long long)todo) - 1;
         const int gt = __builtin_amdgcn_readlane(g, leader);
         const bool mine = pending && g == gt;
-        obsgp_query_group(v, gt, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa);
+        obsgp_query_group(v, gt, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa, sexp);
         pending = pending && !mine;
         __syncthreads();
     }
@@ -258,7 +267,9 @@ __global__ __launch_bounds__(64) void obsgp_query_grouped_kernel(ObsGPView v, co
     __shared__ __attribute__((aligned(16))) float sbuf[64 * 64];
     __shared__ __attribute__((aligned(16))) float sx[128];
     __shared__ __attribute__((aligned(16))) float sa[64];
+    __shared__ f64x2 sexp[64];
     const int lane = threadIdx.x;
+    sexp[lane] = *reinterpret_cast<const f64x2*>(kExp64Tab[lane]);      // (read behind the first barrier of obsgp_query_group)
     const int g = blockIdx.x / kQueryChunks, c0 = blockIdx.x % kQueryChunks;
     const int b = base[g], cnt = count[g];
     for (int chunk = c0; chunk * 64 < cnt; chunk += kQueryChunks) {
@@ -270,7 +281,7 @@ __global__ __launch_bounds__(64) void obsgp_query_grouped_kernel(ObsGPView v, co
             if (v.mode == 2) { q0 = q[2 * qi]; q1 = q[2 * qi + 1]; }
             else q0 = q[qi];
         }
-        obsgp_query_group(v, g, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa);
+        obsgp_query_group(v, g, mine, q0, q1, qi, lane, val, var, sbuf, sx, sa, sexp);
         __syncthreads();
     }
 }

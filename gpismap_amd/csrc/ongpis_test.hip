@@ -1,5 +1,4 @@
-// K4: batched OnGPIS prediction -- mean (value + gradient) and the four variances
-// for tiles of 8 queries against one cluster model.
+// K4: batched OnGPIS prediction -- mean (value + gradient) and the four variances for tiles of 8 queries against one cluster model.
 //
 // Replaces the reference per-point chain
 //   GPisMap3::test_kernel        cpp/src/GPisMap3.cpp:794-902  (2-D: GPisMap.cpp:665-763)
@@ -7,30 +6,21 @@
 //        -> matern32_sparse_deriv1_3D (cross)  cpp/src/covFnc.cpp:258-314 (2-D: :404-450)
 //        -> k*^T alpha ; L^-1 k* ; column sums of squares
 //
-// Work decomposition.  The (1+d) cross-covariance columns of 8 queries form a K x 32 right-hand-side
-// block B.  The reference solves L V = B by substitution -- a chain of K dependent steps.  Here the
-// factor's explicit inverse X = L^-1 comes out of training (K3b, ongpis_train.hip), so
-//     V = X B      (lower-triangular matrix product, 32 x 32 tiles, v_mfma_f32_32x32x2_f32)
-// has NO dependency between its block rows: every wavefront of the workgroup owns a few block rows
-// (accumulators in registers), streams the X tiles of those rows from L2/HBM exactly once and reads the
-// B tiles all wavefronts share from LDS.  alpha rides along as row K of X, so row K of V is the mean
-// k*^T alpha (one ascending fmaf chain) and needs no separate reduction.
-//   * B is generated in chunks of CB column blocks into a THREE-slot LDS ring handed over through LDS counters (round 5): a
-//     wavefront multiplies chunk i as soon as its tiles are counted in, then generates its tile of chunk i+2 (the duty goes
-//     round the wavefronts) once every wavefront is through with the chunk that slot held before.  No workgroup barrier in
-//     the loop: a wavefront may run a chunk ahead of the slowest one, which absorbs the per-chunk imbalance of the
-//     triangular product -- with a barrier per chunk (rounds 2-4: two slots, half of the wavefronts generating before
-//     multiplying, half after) 15 % of the wave-cycles waited there.  The variants that lost (the barrier kernel, an exp
-//     table in LDS, generating-only wavefronts, two X-tile buffers, row-major B tiles, two query sets per workgroup) left
-//     this file in round 6: git history and NOTEBOOK R2-R5 have them with their numbers.
-//   * block rows are dealt to the wavefronts from the largest down, snake-wise (row b costs b+1 tile
-//     products); clusters with more than 4 W block rows run several row groups (B chunks are regenerated
-//     for the later, cheaper groups), so there is no upper limit on K.
-//   * NOT here (round 6, measured and removed): an exp table in GLOBAL memory -- one double per (training point, query) in a
-//     private slot of a per-class scratch buffer, filled in the prologue (N x 8 exponentials instead of K x 8) and fetched by the
-//     generating lanes with two 16-byte loads.  0.770 -> 0.658 of peak on the bench with acquire / release hand-over of the slots
-//     (an L1 invalidate and an L2 write-back per workgroup), 0.678 with relaxed atomics -- and then WRONG: the L1 of a CU keeps
-//     stale lines of a slot across owners.  The generation wavefront waits a full memory round trip per tile.  NOTEBOOK R6.2.
+// The (1+d) cross-covariance columns of 8 queries form a K x 32 right-hand-side block B.  The reference solves L V = B by
+// substitution -- K dependent steps.  Here the factor's explicit inverse X = L^-1 comes out of training (K3b), so V = X B
+// (lower-triangular product, 32 x 32 tiles, v_mfma_f32_32x32x2_f32) has NO dependency between its block rows: every wavefront
+// owns a few block rows (accumulators in registers), streams their X tiles from L2 once and reads the B tiles all wavefronts
+// share from LDS.  alpha rides as row K of X: row K of V is the mean k*^T alpha (one ascending fmaf chain).
+//   * B is generated in chunks of CB column blocks into a THREE-slot LDS ring handed over through LDS counters: a wavefront
+//     multiplies chunk i once its tiles are counted in, then generates its tile of chunk i+2 (the duty goes round) once every
+//     wavefront is through with the slot's previous chunk.  No workgroup barrier in the loop (round 5: 15 % of the wave-cycles
+//     waited at the barrier that used to end every chunk).
+//   * block rows are dealt from the largest down, snake-wise (row b costs b+1 tile products); clusters with more than 4 W block
+//     rows run several row groups (B regenerated for the later, cheaper groups): no upper limit on K.
+//   * every vector instruction of the generation stalls the SIMD's matrix pipe (profiles/r06_pivot_step.txt): the exponential is
+//     table-driven (exp_tab.h), sqrt and the three divisions of a gradient row are the range-restricted ones (tile_solve.h).
+//   * what lost and left this file (git history, NOTEBOOK R2-R6): the barrier kernel, exp tables in LDS and in global memory,
+//     generating-only wavefronts, two X-tile buffers, row-major B tiles, two query sets per workgroup.
 // Per element V[r][j] is ONE fmaf chain from zero over ascending k -- the order of the oracle's tiled mode.
 #include <algorithm>
 #include <cstdlib>

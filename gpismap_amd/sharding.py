@@ -16,6 +16,8 @@ rank runs the same host logic but factorises only its share of the frame's clust
 longest-processing-time partition by K^3, computed identically on every rank), then the packed
 models (what K4 needs: 2 K^2 + 20 K bytes each, records back to back at their own sizes) are
 all-gathered in one collective over slots padded to the largest RANK total.
+*Lead / worker* (`update_lead_worker`, round 6): sharded training with the host logic run ONCE -- rank 0 replays the
+frame and broadcasts what it decided (the frame record), the other ranks apply the record instead of replaying.
 `shard_clusters` is the same partition for harnesses that drive the kernel-level C-ABI themselves
 (BASELINE config 5)."""
 import heapq
@@ -152,6 +154,36 @@ def exchange_models(gm, world, rank, device, host_staged=False):
             gm.shard_unpack(r, allrec[r].data_ptr(), torch.cuda.current_stream().cuda_stream)
     gm.shard_finish()
     return total, sum(nbytes) - nbytes[rank], (world - 1) * max(nbytes), sum(nbytes)
+
+
+def update_lead_worker(gm, depth, pose, world, rank, device, host_staged=False):
+    """One frame of a sharded run with the HOST LOGIC OF update() RUN ONCE: rank 0 (the lead; `gm.set_frame_export()` done)
+    replays the frame, broadcasts the frame record -- slot operations, point mirror, cell lists, jobs with owners, cluster
+    table entries: a few hundred KB to a few MB -- and only then trains its own share; every other rank applies the
+    record (`gm.apply_frame`: K6 on its own device + its share of the training) instead of replaying the frame.  Follow
+    with `exchange_models`.  The record is host data on both ends: over nccl it makes one hop through device memory."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        gm.update(depth, pose)
+        return 0
+    dev = "cpu" if host_staged else device
+    if rank == 0:
+        gm.update(depth, pose)                      # host logic + record; the own share waits
+        rec = gm.frame_record()
+        n = torch.tensor([int(rec.size)], dtype=torch.int64, device=dev)
+        dist.broadcast(n, src=0)
+        payload = torch.from_numpy(rec if rec.size else np.zeros(1, dtype=np.uint8)).to(dev)
+        dist.broadcast(payload, src=0)
+        gm.train_deferred()
+        return int(rec.size)
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=0)
+    payload = torch.empty(max(1, int(n.item())), dtype=torch.uint8, device=dev)
+    dist.broadcast(payload, src=0)
+    gm.apply_frame(payload.cpu().numpy()[:int(n.item())])
+    return int(n.item())
 
 
 def exchange_store_models(st, local_models, world, rank, device, host_staged=False):

@@ -94,6 +94,24 @@ long long gpis3_shard_bytes(void* map, int owner);
 int   gpis3_shard_pack(void* map, void* d_buf, void* hip_stream);
 int   gpis3_shard_unpack(void* map, int owner, const void* d_buf, void* hip_stream);
 int   gpis3_shard_finish(void* map);
+/* One process per GPU, the host logic of update() run ONCE (round 6).  By default every rank of a sharded run replays the whole
+ * frame (tree mutation, ObsGP round trips: the larger half of an update) and only the training is divided.  Alternatively the
+ * LEAD rank (rank 0 of gpis3_set_shard) records what its update() decided and the other ranks apply the record:
+ *   lead:    gpis3_set_frame_export(map, 1) once;  per frame  gpis3_update(...)           host logic, record written, own share NOT trained yet
+ *                                                             n = gpis3_frame_record(map, buf, cap)   (a few hundred KB .. MB: the point mirror dominates)
+ *                                                             ... broadcast buf[0..n) to the workers ...
+ *                                                             gpis3_train_deferred(map)   the lead's own share
+ *   worker:  per frame  gpis3_apply_frame(map, buf, n)        slot operations mirrored (the ids must come out as the lead's), point
+ *                                                             mirror uploaded, K6 on its own device, its share trained
+ *   all:     the exchange as above (gpis3_shard_info / _bytes / _pack / _unpack / _finish).
+ * gpis3_frame_record returns the record's size (copies it when cap suffices); a worker map never calls gpis3_update (it holds no
+ * tree: gpis3_get_points answers on the lead only) and is created for that role: gpis3_apply_frame on a map that has replayed
+ * frames itself returns GPIS_ERR_STATE.  gpis3_stats out[26] (host replays of the last update) is 1 on the lead and 0 on a worker.
+ * reset / loadMap on the lead are not recorded: recreate the workers with it. */
+int   gpis3_set_frame_export(void* map, int on);
+long long gpis3_frame_record(void* map, void* buf, long long cap);
+int   gpis3_train_deferred(void* map);
+int   gpis3_apply_frame(void* map, const void* buf, long long bytes);
 int   gpis3_num_points(void* map);
 int   gpis3_get_points(void* map, float* out3, int cap);        /* GPisMap3::getAllPoints GPisMap3.cpp:951 */
 int   gpis3_get_nodes(void* map, float* out9, int cap);         /* pos3 grad3 val sigx sigg, tree order */

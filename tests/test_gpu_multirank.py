@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _run(world, train, extra=()):
     env = dict(os.environ)
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    port = 29600 + (os.getpid() % 300) + world + (7 if train == "sharded" else 0)
+    port = 29600 + (os.getpid() % 300) + world + (7 if train == "sharded" else (13 if train == "lead" else 0))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--backend", "gloo", "--train", train,
            "--grid", "64", "--frames", "2", "--steps", "1", "--warmup", "0", "--cpu-sample", "0", "--stress", "96", "--block", "4096"] + list(extra)
@@ -46,6 +46,19 @@ def test_bench_rehearsal_is_bit_identical(world, train):
         assert deliv <= 1.1 * rec + 65536, (deliv, rec)             # padding of the shorter ranks' slots
     if world > 1:
         assert st["exchange_bytes_received_per_rank"] > 0
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_lead_worker_update_replays_the_host_logic_once(world):
+    """one process per GPU with the host logic of update() run ONCE.  Rank 0 replays every frame and
+    broadcasts the frame record; the other ranks apply it (slot operations mirrored, K6 + their share of the training on
+    their own device) and never replay.  The assembled map is bit-identical to a single-rank pass (the _run assertion), the
+    host replays summed over the ranks equal the number of frames, and the record is a few MB at most."""
+    d = _run(world, "lead")
+    hr = d["per_rank"]["host_replays"]
+    assert hr[0] == 2 and sum(hr) == 2, hr                       # --frames 2: both on rank 0
+    assert 0 < d["frame_record_bytes_per_frame"] < 16 << 20
+    assert d["exchange_record_bytes_per_frame"] > 0
 
 
 def test_bench_self_launches_from_a_plain_python_call():

@@ -6,7 +6,7 @@
 # Usage (GPU box): tools/measure_traffic.sh          -> results under gpurun_out/, copy into profiles/ afterwards
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-ROUND=${ROUND:-r05}; export ROUND
+ROUND=${ROUND:-r06}; export ROUND
 mkdir -p gpurun_out
 CMD="bench.py --steps 1 --warmup 0 --cpu-sample 0 --stress 0 --no-host-api --update-repeats 1"   # (one fusion per accounting: with three or more AND the side streams of small test() passes in use, rocprofv3 --pmc shows 0.65 GB of extra reads and writes per K4 launch -- profiles/README.md; run time is the same)
 OUT=gpurun_out/${ROUND}_k4_pmc.txt

@@ -1,11 +1,11 @@
 #!/bin/bash
 # GPU box: the round's profile evidence, ONE command: the default bench line, its kernel stats (checked against the line), K4
 # traffic / counters, stress kernel stats and counters, the update() counters / timeline / pipelined timing, the K4 efficiency
-# curve, the bundled sequences.  Results under gpurun_out/ (copy into profiles/).  Usage: ROUND=r05 bash tools/r5_profiles.sh [quick]
+# curve, the bundled sequences.  Results under gpurun_out/ (copy into profiles/).  Usage: ROUND=r06 bash tools/round_profiles.sh [quick]
 # EXIT CODE 3 when the kernel-stats file contradicts the bench line it belongs to (sum of K4 per pass > ms_per_step).
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-export ROUND=${ROUND:-r05}
+export ROUND=${ROUND:-r06}
 R=$ROUND
 # The kernel-stats collection runs the SAME bench command with one update fusion and the size-class launches of small test() passes
 # on one stream: with several fusions and the forked side streams the process holds more HIP streams than hardware queues, and the
@@ -23,14 +23,14 @@ for l in txt.splitlines():
     if l.startswith("{") and '"ms_per_step"' in l:
         line = json.loads(l)
 if line is None:
-    print("r5_profiles: no bench line at the end of %s" % p); sys.exit(3)
+    print("round_profiles: no bench line at the end of %s" % p); sys.exit(3)
 passes = line["steps"] + line["warmup"]
 k4_pass = k4 / 1e6 / passes
 head = "# K4<8,...> per 256^3 pass from this trace: %.1f ms (sum / %d passes); ms_per_step of the SAME run: %.1f; collected with GPIS_K4_SERIAL=1 --update-repeats 1\n" % (k4_pass, passes, line["ms_per_step"])
 open(p, "w").write(head + txt)
 print(head.strip())
 if k4_pass > 1.02 * line["ms_per_step"]:
-    print("r5_profiles: INCONSISTENT kernel stats (K4 per pass exceeds the step): do not commit this file"); sys.exit(3)
+    print("round_profiles: INCONSISTENT kernel stats (K4 per pass exceeds the step): do not commit this file"); sys.exit(3)
 PY
 rc=$?
 if [ $rc != 0 ]; then echo "kernel-stats check failed ($rc)"; [ "$1" = quick ] || exit 3; fi

@@ -1,7 +1,7 @@
 #!/bin/bash
 # 8-GPU node (driver): the scaling curve and the checks the one-GPU box cannot do over RCCL.
 #   tools/scale_check.sh [max_gpus]        default 8
-# For N = 1, 2, 4, 8 and both training modes: `python3 bench.py --gpus N --verify` -- prints the bench line's value, per-rank
+# For N = 1, 2, 4, 8 and the three training modes (replicated, sharded, lead = sharded with update()'s host logic run once on rank 0): `python3 bench.py --gpus N --verify` -- prints the bench line's value, per-rank
 # GP evaluations, K4 ms, pass / gather / exchange ms, and FAILS if the assembled 256^3 map differs by a bit from rank 0's
 # single-rank pass on a 64^3 sub-grid (bench.py --verify raises).  Then the in-library multi-device map (one process, N
 # devices: gpis3_create_multi) against a one-device map.  Logs: gpurun_out/scale_*.json.
@@ -12,8 +12,8 @@ mkdir -p gpurun_out
 export HSA_ENABLE_IPC_MODE_LEGACY=0
 for N in 1 2 4 8; do
   [ $N -gt $MAXN ] && break
-  for MODE in replicated sharded; do
-    [ $N -eq 1 ] && [ $MODE = sharded ] && continue
+  for MODE in replicated sharded lead; do
+    [ $N -eq 1 ] && [ $MODE != replicated ] && continue
     OUT=gpurun_out/scale_${N}_${MODE}.json
     python3 bench.py --gpus $N --train $MODE --verify --cpu-sample 0 --stress 0 --no-host-api > $OUT
     python3 - "$OUT" $N $MODE <<'PY'
@@ -30,6 +30,7 @@ if d.get("exchange_record_bytes_per_frame"):
     print("   exchange: records %.3f GB/frame, received per rank %.3f GB, %.2f ms/frame -> %.1f GB/s into each rank, %.3f GB and %.1f GB/s per link"
           % (rec / 1e9, got / 1e9, ms, got / 1e6 / ms, rec / n / 1e9, rec / n / 1e6 / ms))
 print("   gp_evals/rank", [round(v / 1e6, 2) for v in pr["gp_evals"]], "M   k4_ms", [round(v, 1) for v in pr["k4_ms_per_step"]])
+print("   host replays of update() per rank over the last fusion", pr.get("host_replays"), " frame record %.2f MB/frame" % (d.get("frame_record_bytes_per_frame", 0) / 1e6))
 if "pass_ms" in pr:
     print("   pass_ms", [round(v, 1) for v in pr["pass_ms"]], " gather_ms", [round(v, 1) for v in pr["gather_ms"]], " exchange_ms", [round(v, 1) for v in pr["exchange_ms_per_frame"]],
           " identical", pr.get("assembled_equals_single_rank_on_64cubed"))

@@ -3,7 +3,7 @@
 # Usage (GPU box): tools/stress_pmc.sh [clusters]   -> gpurun_out/${ROUND}_stress_pmc.txt
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-ROUND=${ROUND:-r05}; export ROUND
+ROUND=${ROUND:-r06}; export ROUND
 mkdir -p gpurun_out
 NCL=${1:-50000}
 OUT=gpurun_out/${ROUND}_stress_pmc.txt
