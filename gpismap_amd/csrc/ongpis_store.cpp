@@ -588,6 +588,21 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
             kCoopMaxWG = std::min(kCoopMaxWG, std::max(2, (ncu - cu_reserve_) - (ncu - cu_reserve_) / 16));
     }
     int kCoopGDiv = 900, kCoopGMax = 6;
+    // Round 6: the numbers above are the THROUGHPUT schedule (a frame of several hundred large clusters fills the device with
+    // one workgroup each; tuned on the synthetic frames).  A batch that cannot fill the device is bound by the LATENCY of its
+    // largest clusters instead -- the reference's own sequence trains 20-60 clusters per frame -- and there more cooperating
+    // workgroups per cluster win: one K = 1190 cluster 1.73 ms with 2 workgroups, 1.37 with 3, 1.09 with 6, 1.02 with 13; eight
+    // K = 680 clusters 0.71 ms alone, 0.58 as pairs; on data/3D the K3 chain per frame 3.39 -> 2.27 ms (median of 39 frames,
+    // sum 134 -> 99 ms; tools/ab sweep of K3_MINNB / K3_GDIV / K3_GMAX in an instrumented build, profiles/r06_k3_coop_sweep.txt).
+    // G ~ nb^2 / 112 was faster still on single clusters but produced 13-17 ms outlier frames (sixteen workgroups of one cluster
+    // waiting for residency beside the one-workgroup kernel's clusters).
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, coop_dev) != hipSuccess) ncu = 256;
+        const int avail = std::max(8, ncu - std::max(0, cu_reserve_));
+        if (n0 <= avail / 4) { kCoopMinNb = 16; kCoopGDiv = 225; kCoopGMax = 16; }
+        else if (n0 <= avail / 2) { kCoopGDiv = 450; kCoopGMax = 8; }
+    }
     int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
 #include "ongpis_store_instr.inc"   // schedule knobs from the environment (tuning sweeps only)
