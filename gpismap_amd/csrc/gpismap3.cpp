@@ -1121,6 +1121,24 @@ int GPisMap3::Impl::apply_frame(const char* buf, size_t bytes) {
     const ClusterEntry* ent = rd.take<ClusterEntry>((size_t)h.n_ent);
     const AncestorEntry* anc = rd.take<AncestorEntry>((size_t)h.n_anc);
     if (!rd.ok || h.n_desc % 8 != 0 || h.n_counts != h.n_desc / 4 || h.n_cr % 2 != 0) return GPIS_ERR_ARG;
+    {   // the index structures the device pass will follow: every range inside its array (a damaged record is refused, not walked)
+        const long long ncr = (long long)(h.n_cr / 2), ncp = (long long)h.n_cell_pts, npts = (long long)h.np;
+        for (size_t i = 0; i < h.n_cell_pts; ++i) if (cell_pts[i] < 0 || cell_pts[i] >= npts) return GPIS_ERR_ARG;
+        for (long long i = 0; i < ncr; ++i) if (cr[2 * i] < 0 || cr[2 * i] > cr[2 * i + 1] || cr[2 * i + 1] > ncp) return GPIS_ERR_ARG;
+        long long cap_sum = 0;
+        for (size_t i = 0; i < h.n_desc / 8; ++i) {
+            const long long e0 = desc[8 * i], ne = desc[8 * i + 1], off = desc[8 * i + 2];
+            if (e0 < 0 || ne < 0 || e0 + ne > ncr || off != cap_sum) return GPIS_ERR_ARG;
+            for (long long e = e0; e < e0 + ne; ++e) cap_sum += cr[2 * e + 1] - cr[2 * e];
+        }
+        if (h.total < 0 || cap_sum != (long long)h.total) return GPIS_ERR_ARG;
+        for (size_t j = 0; j < h.n_jobs; ++j)
+            if (jobs[j].n <= 0 || jobs[j].ng < 0 || jobs[j].ng > jobs[j].n || jobs[j].off < 0 ||
+                (long long)jobs[j].off + jobs[j].n > (h.device_gather ? (long long)h.total : (long long)h.n_ids)) return GPIS_ERR_ARG;
+        for (size_t i = 0; i < h.n_ids; ++i) if (ids[i] < 0 || ids[i] >= npts) return GPIS_ERR_ARG;
+        for (size_t i = 0; i < h.n_ent; ++i) if (ent[i].parent < -1 || ent[i].parent >= (int)h.n_anc) return GPIS_ERR_ARG;
+        for (size_t i = 0; i < h.n_anc; ++i) if (anc[i].parent < -1 || anc[i].parent >= (int)h.n_anc) return GPIS_ERR_ARG;
+    }
     stat_host_replays = 0;
     if (h.nothing) { shard_jobs.clear(); table_pending = false; upd_rc = 0; return GPIS_OK; }
     stat_deferred_inverses = 0;

@@ -52,7 +52,8 @@ size_t chunk_cache_limit() {
 // Round 6: the pool grows OFF the caller's thread.  A 512 MiB hipMalloc costs 5-10 ms, and a fresh process paid it inside the
 // update() calls that grew the map (profiles/r05_update_pipeline.txt, first repeat: frames of 40-58 ms where a warm process
 // takes 17).  A helper thread keeps spare chunks in the per-device cache ahead of the demand: as soon as a pool of a device
-// takes its first chunk, the helper allocates until the cache holds max(4, half of what the device's pools hold) chunks
+// takes its first chunk, the helper allocates until the cache holds max(8, as many as the device's pools hold) chunks -- a growing
+// map takes three or four chunks per frame, one hipMalloc takes as long as a frame: the reserve is built while the demand is low
 // (bounded by GPIS_POOL_CACHE_GB like the cache itself), and tops it up whenever a pool takes one.  A pool that finds the cache
 // empty still allocates for itself, as before.  gpis_pool_cache_trim() parks the helper until the next pool grows;
 // GPIS_POOL_PREFETCH=0 turns it off.  The helper never touches a stream: hipMalloc on its own thread.
@@ -70,7 +71,7 @@ bool prefetch_enabled() {
 }
 size_t prefetch_target(int dev) {      // (g_chunk_mu held)
     if (!g_pf.active[dev]) return 0;
-    return std::min(chunk_cache_limit(), std::max((size_t)4, g_pf.handed[dev] / 2));
+    return std::min(chunk_cache_limit(), std::max((size_t)8, g_pf.handed[dev]));
 }
 void prefetch_main() {
     std::unique_lock<std::mutex> lk(g_chunk_mu);

@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
                     // refined reciprocal (tile_solve.h div_ranged: the bits of `/`; r = 0 -- a query ON a training point -- gives the
                     // reference's NaN)
                     const float ri = rcp_refined(rr);
-                    auto kf2 = [&](float dx1, float dx2, float delta) { return (float)((double)(a * a * (delta - div_ranged(a * dx1 * dx2, rr, ri))) * e); };
+                    auto kf2 = [&](float dx1, float dx2, float delta) { return (float)((double)(a * a * (delta - div_ranged_anyzero(a * dx1 * dx2, rr, ri))) * e); };   // (delta - (+-0) is delta either way)
                     v1 = (cr == 1) ? kf2(d[0], d[0], 1.0f) : kf2(d[0], dr, 0.0f);
                     v2 = (cr == 2) ? kf2(d[1], d[1], 1.0f) : (cr == 1 ? kf2(d[0], d[1], 0.0f) : kf2(d[1], d[2], 0.0f));
                     v3 = (cr == 3) ? kf2(d[2], d[2], 1.0f) : kf2(dr, d[2], 0.0f);

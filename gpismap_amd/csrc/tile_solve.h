@@ -44,6 +44,15 @@ __device__ __forceinline__ float div_ranged(float a, float d, float r) {        
     q = fmaf(e, r, q);
     return (a == 0.f) ? q0 : q;             // (+-0 / d: the zero of the right sign -- and NaN for 0 / 0, where r is NaN -- is the first product)
 }
+// ... for callers that only ADD the quotient to something non-zero or take it times something: a zero quotient may come out with
+// either sign (0 / 0 is still NaN: every step carries r's NaN along)
+__device__ __forceinline__ float div_ranged_anyzero(float a, float d, float r) {
+    const float q0 = a * r;
+    float e = fmaf(-d, q0, a);
+    float q = fmaf(e, r, q0);
+    e = fmaf(-d, q, a);
+    return fmaf(e, r, q);
+}
 
 // In-register solve of the 32x32 lower-triangular system for the 32 columns of a
 // tile held in MFMA C/D layout (lane = column, 16 of the 32 rows per lane half).

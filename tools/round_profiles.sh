@@ -43,6 +43,20 @@ bash tools/update_pmc.sh sq > /dev/null 2>&1; cat gpurun_out/update_pmc.txt >> g
 bash tools/update_timeline.sh 5 > /dev/null 2>&1; { cat gpurun_out/update_profile.txt; grep -E "ongpis|obsgp|fused" gpurun_out/update_timeline.txt; } > gpurun_out/${R}_update_timeline.txt
 python3 tools/update_pipeline.py 8 2>&1 | tail -5 > gpurun_out/${R}_update_pipeline.txt
 bash tools/k4_curve.sh > /dev/null 2>&1
+# K4 cycle stamps (instrumented build, tools/ab/lib_instr.so = `bash tools/ab_full.sh instr -DGPIS_INSTRUMENT` of the same source): bench pass, then two small sizes
+if [ -f tools/ab/lib_instr.so ]; then
+  rm -f gpurun_out/k4_trace.txt
+  GPISMAP_AMD_LIB=$PWD/tools/ab/lib_instr.so python3 bench.py --steps 1 --warmup 0 --cpu-sample 0 --no-host-api --update-repeats 1 --stress 0 > /dev/null 2>&1
+  python3 tools/k4_trace_summary.py gpurun_out/k4_trace.txt 1000 > gpurun_out/${R}_k4_stamps.txt 2>&1
+  for N in 60 120 300; do
+    rm -f gpurun_out/k4_trace.txt
+    GPISMAP_AMD_LIB=$PWD/tools/ab/lib_instr.so python3 tools/k4_bench.py $N 64 8192 1 > /dev/null 2>&1
+    echo "== k4_bench N=$N (64 clusters x 8192 queries)" >> gpurun_out/${R}_k4_stamps.txt
+    python3 tools/k4_trace_summary.py gpurun_out/k4_trace.txt 1000 | tail -1 >> gpurun_out/${R}_k4_stamps.txt
+  done
+fi
+# the pivot step of the in-register Cholesky (tools/ubench/pivot_chain.hip; profiles/r06_pivot_step.txt holds the round's annotated copy)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Igpismap_amd/csrc -Iinclude tools/ubench/pivot_chain.hip -o /tmp/pivot_chain > /dev/null 2>&1 && /tmp/pivot_chain > gpurun_out/${R}_pivot_step_raw.txt 2>&1
 { python3 tools/seq_bench.py --gpu-alone; python3 tools/seq_bench.py; } > gpurun_out/${R}_seq_bench.txt 2>&1
 mkdir -p profiles; cp gpurun_out/${R}_k4_traffic.json profiles/ 2>/dev/null     # (bench.py reports roofline.traffic from it while ongpis_test.hip keeps its sha)
 python bench.py > gpurun_out/${R}_bench_line.json 2> gpurun_out/${R}_bench_err.txt
