@@ -160,7 +160,7 @@ __device__ __forceinline__ void obsgp_query_group(const ObsGPView& v, int gt, bo
 #pragma unroll 1
             for (int i = 0; i < n; ++i) {
                 // d_ou_k(d_dist2(...)) with the table-driven exponential (exp_tab.h) and the range-restricted square root (tile_solve.h):
-                // the exponentials were more than half of this kernel's instruction issue
+                // (half of this kernel's vector instructions; its run time did not move -- it waits on the LDS reads of the substitution)
                 const float tx_ = sx[2 * i] - q0, ty_ = sx[2 * i + 1] - q1;
                 sbuf[i * 64 + lane] = (float)exp_neg_tab(-a * sqrt_ranged(tx_ * tx_ + ty_ * ty_), sexp);
             }
