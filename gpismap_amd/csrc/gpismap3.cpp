@@ -303,6 +303,17 @@ struct GPisMap3::Impl {
     // answers, the pose and the settings (data-parallel over the points of the frame: host_pool.h); reeval_commit applies the
     // outcome to the tree (sequential, in the reference's order).  reeval_apply = both, for the late arrivals.
     struct ReevalOut { int kind = 0; float pos[3], grad[3], noise = 0.f, gnoise = 0.f; };   // 0 nothing, 1 inflate the noises, 2 move the point
+    // Per-frame work arrays of update() kept across frames (round 6): ~9 MB of them were allocated and freed every frame, and glibc
+    // gives freed memory of that size back to the system -- every frame paid the page faults and the zeroing again (a run with
+    // MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ raised: about 1 ms per frame).  Same contents, capacity retained.
+    std::vector<int> ws_ids, ws_slot, ws_nodes, ws_late;
+    std::vector<Stage2> ws_st;
+    std::vector<float> ws_pval, ws_pvar, ws_val, ws_var;
+    std::vector<ReevalOut> ws_outs;
+    std::vector<char> ws_front;
+    std::vector<std::array<float, 3>> ws_loc;
+    T3::CellLists ws_cells;
+    std::vector<std::vector<int>> ws_touched, ws_plist;
     ReevalOut reeval_math(const FlatPoint<3>& nd, const Stage2& st, const float* pval, const float* pvar) const;
     void reeval_commit(int pid, const ReevalOut& o);
     void reeval_apply(int pid, const Stage2& st, const float* pval, const float* pvar);
@@ -430,8 +441,9 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     // both K2 batches go through the ObsGP object's page-locked staging, sized once for the larger (6 n) one
     float* q = gpo.stage_q(6 * n);
     if (!q) { fprintf(stderr, "[gpismap_amd] ObsGP staging allocation failed\n"); if (!upd_rc) upd_rc = GPIS_ERR_HIP; return; }
-    std::vector<char> front(n, 0);
-    std::vector<std::array<float, 3>> loc(n);
+    std::vector<char>& front = ws_front;
+    std::vector<std::array<float, 3>>& loc = ws_loc;
+    front.assign(n, 0); loc.resize(n);
     // (both host loops below are pure per point: on the host threads, host_pool.h)
     pool().parallel_for(n, [&](int lo_, int hi_) {
     for (int i = lo_; i < hi_; ++i) {
@@ -450,7 +462,8 @@ void GPisMap3::Impl::reeval_batch(const std::vector<int>& ids, std::vector<Stage
     stat_obs_queries += n;
     const float delx = setting.delx;
     // centre answers: copied out, the staging is reused for the perturbation batch
-    std::vector<float> val(gpo.staged_val(), gpo.staged_val() + n), var(gpo.staged_var(), gpo.staged_var() + n);
+    std::vector<float>& val = ws_val; std::vector<float>& var = ws_var;
+    val.assign(gpo.staged_val(), gpo.staged_val() + n); var.assign(gpo.staged_var(), gpo.staged_var() + n);
     float* q2 = q;
     std::fill(q2, q2 + (size_t)12 * n, 1e30f);
     pool().parallel_for(n, [&](int lo_, int hi_) {
@@ -648,26 +661,29 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
     if (sel.empty()) return;
 
     // speculative batch over every point currently stored in the selected clusters
-    std::vector<int> ids;
+    std::vector<int>& ids = ws_ids;
+    ids.clear();
     for (int c : sel) tree.all_points(c, ids);
-    std::vector<Stage2> st;
-    std::vector<float> pval, pvar;
+    std::vector<Stage2>& st = ws_st;
+    std::vector<float>& pval = ws_pval; std::vector<float>& pvar = ws_pvar;
     ulap("reEvalPoints: select");
     reeval_batch(ids, st, pval, pvar);
     ulap("reEvalPoints: K2 batches");
     launch_pixel_batch();      // the new-pixel batch runs on the device while the host replays the re-evaluation below
-    std::vector<int> slot(tree.pts.size(), -1);
+    std::vector<int>& slot = ws_slot;
+    slot.assign(tree.pts.size(), -1);
     for (size_t i = 0; i < ids.size(); ++i) slot[ids[i]] = (int)i;
     // the fusion arithmetic of every point of the batch on the host threads (a point's outcome depends on its own state only,
     // and no commit below touches another stored point's data); the tree replay then applies the outcomes in order
-    std::vector<ReevalOut> outs(ids.size());
+    std::vector<ReevalOut>& outs = ws_outs;
+    outs.resize(ids.size());
     pool().parallel_for((int)ids.size(), [&](int lo, int hi) {
         for (int i = lo; i < hi; ++i) outs[i] = reeval_math(tree.pts[ids[i]], st[i], &pval[(size_t)6 * i], &pvar[(size_t)6 * i]);
     });
     ulap("reEvalPoints: fusion arithmetic");
 
     // replay in the reference's order; node lists are fetched lazily per cluster (:308-311)
-    std::vector<int> nodes, late;
+    std::vector<int>& nodes = ws_nodes; std::vector<int>& late = ws_late;
     for (int c : sel) {
         nodes.clear();
         tree.all_points(c, nodes);
@@ -916,7 +932,7 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         std::sort(todo.begin(), todo.end());
         std::vector<TrainJob> jobs;
         std::vector<int> ids, res;
-        T3::CellLists cell_lists;   // the points of every touched cell listed once for the whole batch (flat_tree.h)
+        T3::CellLists& cell_lists = ws_cells;   // the points of every touched cell listed once for the whole batch (flat_tree.h)
         cell_lists.reset(tree.nodes.size());
         store.defer_finish = pipeline && shard_world == 1 && peers.empty();
         int rc = GPIS_OK;
@@ -941,10 +957,12 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
         if (rc == GPIS_OK && device_gather) {
             // K6 range part on the device: the host only names the cells (traversal order) and lists each touched cell once
             // the cell walks of the frame's clusters on the host threads (read-only, independent), the listing in cluster order
-            std::vector<std::vector<int>> touched(todo.size());
+            std::vector<std::vector<int>>& touched = ws_touched;
+            if (touched.size() < todo.size()) touched.resize(todo.size());
             pool().parallel_for((int)todo.size(), [&](int lo_, int hi_) {
                 for (int i = lo_; i < hi_; ++i) {
                     const int c = todo[i];
+                    touched[i].clear();
                     tree.query_clusters(tree.root, tree.nodes[c].c, tree.nodes[c].h * kRtimes, touched[i], nullptr);
                 }
             }, 16);
@@ -953,14 +971,15 @@ void GPisMap3::Impl::updateGPs() {  // GPisMap3.cpp:698-792 -> K6 + K3
                 // serial pass would first meet them, their point lists in parallel, laid out back to back by a prefix sum --
                 // cell_lists then holds exactly what range_cells_from() would have built on the fly
                 std::vector<int> order;
-                for (const std::vector<int>& tc : touched)
-                    for (int cell : tc) if (cell_lists.begin[cell] == -1) { cell_lists.begin[cell] = -2; order.push_back(cell); }
-                std::vector<std::vector<int>> plist(order.size());
+                for (size_t ti = 0; ti < todo.size(); ++ti)
+                    for (int cell : touched[ti]) if (cell_lists.begin[cell] == -1) { cell_lists.begin[cell] = -2; order.push_back(cell); }
+                std::vector<std::vector<int>>& plist = ws_plist;
+                if (plist.size() < order.size()) plist.resize(order.size());
                 pool().parallel_for((int)order.size(), [&](int lo_, int hi_) {
-                    for (int i = lo_; i < hi_; ++i) tree.all_points(order[i], plist[i]);
+                    for (int i = lo_; i < hi_; ++i) { plist[i].clear(); tree.all_points(order[i], plist[i]); }
                 }, 16);
                 size_t tot = cell_lists.pts.size();
-                for (const std::vector<int>& pl : plist) tot += pl.size();
+                for (size_t i = 0; i < order.size(); ++i) tot += plist[i].size();
                 cell_lists.pts.reserve(tot);
                 for (size_t i = 0; i < order.size(); ++i) {
                     cell_lists.begin[order[i]] = (int)cell_lists.pts.size();
@@ -1570,7 +1589,7 @@ bool GPisMap3::test_one(float* x, int dim, int leng, float* res) try {
 void GPisMap3::getAllPoints(std::vector<float>& pos) try {  // GPisMap3.cpp:951-972
     pos.clear();
     Impl& m = *p_;
-    if (!m.has_tree) return;
+    if (!m.has_tree || m.tree.root < 0) return;      // (a worker -- device or process -- answers test() from the lead's index and holds no tree)
     std::vector<int> ids;
     m.tree.all_points(m.tree.root, ids);
     pos.reserve(ids.size() * 3);
@@ -1580,7 +1599,7 @@ void GPisMap3::getAllPoints(std::vector<float>& pos) try {  // GPisMap3.cpp:951-
 void GPisMap3::getAllNodes(std::vector<float>& out) try {
     out.clear();
     Impl& m = *p_;
-    if (!m.has_tree) return;
+    if (!m.has_tree || m.tree.root < 0) return;
     std::vector<int> ids;
     m.tree.all_points(m.tree.root, ids);
     out.reserve(ids.size() * 9);
@@ -1715,7 +1734,7 @@ bool ckpt_read(const char* path, const FlatTreeParam& q, CkptImage& im) {
 
 bool GPisMap3::saveMap(const char* path) try {
     Impl& m = *p_;
-    if (!path || !m.ok) return false;
+    if (!path || !m.ok || m.remote_index) return false;      // (a worker process holds no tree: the checkpoint is the lead's to write)
     DeviceScope ds(m.device);
     if (m.finish_training() != GPIS_OK || m.table_pending) return false;
     std::vector<int> cl, cells;
