@@ -2,6 +2,7 @@
 // the compiler's own correctly rounded sqrtf and `/` on the same device: counts the operand pairs whose bits differ.
 // C-ABI: gpis_selftest_ranged_arith (include/gpismap_amd.h); tests/test_gpu_ongpis.py.
 #include "tile_solve.h"
+#include "exp_tab.h"
 
 namespace gpis {
 
@@ -44,6 +45,30 @@ __global__ void selftest_ranged_kernel(unsigned long long seed, int per_thread, 
     atomicAdd(out + 1, bad_div);
 }
 
+// mode 2: the table-driven exponential of the kernels' generation (exp_tab.h) against the device library's exp on arguments -a r
+// in [-12, 0] (and a few far below): out[0] = results more than one ulp apart (none: each is within about half an ulp of the truth),
+// out[1] = results that differ at all (last-bit disagreements, a fraction of a per cent)
+__global__ void selftest_exp_kernel(unsigned long long seed, int per_thread, unsigned long long* out) {
+    __shared__ f64x2 tab[64];
+    if (threadIdx.x < 64) tab[threadIdx.x] = *reinterpret_cast<const f64x2*>(kExp64Tab[threadIdx.x]);
+    __syncthreads();
+    unsigned long long s = seed + 0x7654321ull * (blockIdx.x * blockDim.x + threadIdx.x + 1);
+    unsigned long long far = 0, any = 0;
+    for (int i = 0; i < per_thread; ++i) {
+        const unsigned u = st_rng(s);
+        float x = -12.0f * (float)(u >> 8) * (1.0f / 16777216.0f);
+        if ((u & 255u) == 0) x = -700.0f - (float)(st_rng(s) & 127u);     // deep underflow region and below -745
+        if ((u & 255u) == 1) x = -0.0f;
+        const double a = exp((double)x), b = exp_neg_tab(x, tab);
+        const long long ia = __double_as_longlong(a), ib = __double_as_longlong(b);
+        const long long d = ia > ib ? ia - ib : ib - ia;
+        if (d > 1) ++far;
+        if (d != 0) ++any;
+    }
+    atomicAdd(out, far);
+    atomicAdd(out + 1, any);
+}
+
 // -> mismatches[0] = square roots, [1] = divisions, of blocks * 256 * per_thread operand pairs
 int selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, int mode, unsigned long long* mismatches) {
     if (blocks < 1 || per_thread < 1 || !mismatches) return GPIS_ERR_ARG;
@@ -51,7 +76,8 @@ int selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, i
     GPIS_HIP(hipMalloc(&d, 2 * sizeof(unsigned long long)));
     hipError_t e = hipMemset(d, 0, 2 * sizeof(unsigned long long));
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(selftest_ranged_kernel, dim3(blocks), dim3(256), 0, 0, seed, per_thread, mode, d);
+        if (mode == 2) hipLaunchKernelGGL(selftest_exp_kernel, dim3(blocks), dim3(256), 0, 0, seed, per_thread, d);
+        else hipLaunchKernelGGL(selftest_ranged_kernel, dim3(blocks), dim3(256), 0, 0, seed, per_thread, mode, d);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpy(mismatches, d, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost);

@@ -237,7 +237,9 @@ int   gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms);
  * (csrc/tile_solve.h: the compiler's correctly rounded expansions without the operand scaling and classification the chains'
  * operands never need).  Runs blocks * 256 * per_thread random operand pairs through them and through the compiler's sqrtf and `/`
  * on the current device and returns the number of results whose bits differ: mismatches2[0] square roots, [1] divisions.
- * mode 0: the documented operand ranges; mode 1: operands shaped like the factorisations'. */
+ * mode 0: the documented operand ranges; mode 1: operands shaped like the factorisations'; mode 2: the table-driven double-precision
+ * exponential of the prediction / query kernels (csrc/exp_tab.h) against the device library's exp on arguments in [-12, 0] and a
+ * few deep in the underflow range: mismatches2[0] = results more than one ulp apart, [1] = results that differ at all. */
 int   gpis_selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, int mode, unsigned long long* mismatches2);
 int   gpis_ongpis_last_ms(void* s, float* train_ms, float* eval_ms);
 

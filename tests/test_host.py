@@ -237,3 +237,22 @@ def test_no_kernel_spills_or_uses_scratch():
     assert not [names[k] for k in t if "eval_small" in names[k] or "chol_async" in names[k]]
     # the dominant kernel keeps its occupancy: K4 at most 128 VGPRs (4 wavefronts per SIMD)
     assert all(r["vgpr"] <= 128 for k, r in t.items() if "ongpis_eval_kernel" in names[k])
+
+
+def test_exp_table_of_the_kernels_matches_its_generator():
+    """csrc/exp_tab.h (the table-driven double-precision exponential of K4's and K2's generation, round 6) holds a 64-entry table
+    of 2^(j/64) as (hi, lo) pairs and the reduction constants; tools/exp_table.py generates them with 80-digit arithmetic and
+    checks the scheme against the 80-digit exponential.  The committed header must carry exactly the generator's values, and the
+    scheme must stay within 0.52 ulp on its working range."""
+    import re
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "exp_table.py")], capture_output=True, text=True, check=True).stdout
+    gen_rows = re.findall(r"\{(-?0x[0-9a-fp.+-]+), (-?0x[0-9a-fp.+-]+)\}", out)
+    hdr = open(os.path.join(ROOT, "gpismap_amd", "csrc", "exp_tab.h")).read()
+    hdr_rows = re.findall(r"\{(-?0x[0-9a-fp.+-]+), (-?0x[0-9a-fp.+-]+)\}", hdr)
+    assert len(gen_rows) == 64 and hdr_rows == gen_rows
+    consts = re.search(r"64 / ln 2 = (\S+) ; ln 2 / 64 = (\S+) \+ (\S+)", out).groups()
+    for c in consts:
+        assert c in hdr or ("-" + c) in hdr, c
+    worst = float(re.search(r"worst error ([0-9.]+) ulp", out).group(1))
+    assert worst <= 0.52
