@@ -90,6 +90,9 @@ def lib():
     L.gpis2_test_device.argtypes = [vp, vp, C.c_int, vp, vp]
     L.gpis2_get_nodes.argtypes = [vp, fp, C.c_int]
     L.gpis2_stats.argtypes = [vp, dp, C.c_int]
+    if hasattr(L, "gpis2_sync"):
+        L.gpis2_sync.argtypes = [vp]
+        L.gpis2_set_pipeline.argtypes = [vp, C.c_int]
     L.gpis_obsgp_create.restype = vp
     L.gpis_obsgp_destroy.argtypes = [vp]
     L.gpis_obsgp_train2d.argtypes = [vp, fp, fp, C.c_int, C.c_int]
@@ -397,6 +400,13 @@ class GPisMap:
         a = (C.c_double * 12)()
         _check(self.L.gpis2_stats(self.h, a, 12), "gpis2_stats")
         return dict(zip(GPisMap3.STAT_KEYS, list(a)))
+
+    def sync(self):
+        """Join the training the last update() left in flight (pipelined mode); raises when it failed."""
+        _check(self.L.gpis2_sync(self.h), "gpis2_sync")
+
+    def set_pipeline(self, on=True):
+        _check(self.L.gpis2_set_pipeline(self.h, 1 if on else 0), "gpis2_set_pipeline")
 
 
 class ObsGP:

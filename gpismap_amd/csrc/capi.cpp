@@ -40,6 +40,8 @@ long long gpis3_impl_frame_record(GPisMap3* g, void* buf, long long cap);
 int gpis3_impl_train_deferred(GPisMap3* g);
 int gpis3_impl_apply_frame(GPisMap3* g, const void* buf, long long bytes);
 int gpis2_impl_device(GPisMap* m);
+int gpis2_impl_sync(GPisMap* m);
+void gpis2_impl_set_pipeline(GPisMap* m, int on);
 
 namespace gpis { int selftest_ranged_arith(unsigned long long seed, int blocks, int per_thread, int mode, unsigned long long* mismatches); }
 extern "C" {
@@ -192,6 +194,8 @@ int gpis2_test_device(void* m, const float* d_x, int n, float* d_res, void* stre
     catch (...) { return GPIS_ERR_STATE; }
 }
 int gpis2_device(void* m) { if (!m) return GPIS_ERR_ARG; return gpis2_impl_device((GPisMap*)m); }
+int gpis2_sync(void* m) { if (!m) return GPIS_ERR_ARG; try { return gpis2_impl_sync((GPisMap*)m); } catch (...) { return GPIS_ERR_STATE; } }
+int gpis2_set_pipeline(void* m, int on) { if (!m) return GPIS_ERR_ARG; try { gpis2_impl_set_pipeline((GPisMap*)m, on); } catch (...) { return GPIS_ERR_STATE; } return GPIS_OK; }
 int gpis2_get_nodes(void* m, float* out, int cap) {
     if (!m) return GPIS_ERR_ARG;
     std::vector<float> p; ((GPisMap*)m)->getAllNodes(p);

@@ -6,9 +6,11 @@
 //     e^x = 2^m * 2^(j/64) * e^r ,   2^(j/64) from a 64-entry (hi, lo) table, e^r - 1 by a degree-6 polynomial,
 // 15 double-rate instructions instead of 26 (the prediction kernel's matrix pipe idles while ANY vector instruction of its
 // SIMD issues: tools/ubench/pivot_chain.hip, NOTEBOOK R6.3 -- the exponentials were 40 % of the generation's issue cycles).
-// Accuracy: <= 0.51 ulp on [-12, 0] against 80-digit arithmetic (tools/exp_table.py, which also generates the table); it
-// differs from glibc's result in the last bit for ~0.3 % of the arguments, as the device library's did, and a kernel entry
-// (float)(coefficient * e) then differs only when that bit straddles a float rounding boundary (~2^-29 of those).
+// Accuracy: <= 0.51 ulp on [-12, 0] against 80-digit arithmetic (tools/exp_table.py, which also generates the table): it misses
+// the correctly rounded result for 0.2 % of the arguments (glibc's exp 0.1 %; the device library's differs from this one in the
+// last bit for 6 % of them -- gpis_selftest_ranged_arith mode 2 -- so it was the least accurate of the three), and a kernel
+// entry (float)(coefficient * e) differs from the oracle's only when such a last bit straddles a float rounding boundary
+// (~2^-29 of those).
 // Arguments below -745 give 0; NaN stays NaN.
 #pragma once
 #include <hip/hip_runtime.h>

@@ -66,12 +66,25 @@ struct GPisMap::Impl {
     float range_obs_max = 0.f;
     float* d_x = nullptr; float* d_res = nullptr; size_t cap_x = 0, cap_res = 0;
     long stat_obs_queries = 0, stat_clusters_trained = 0, stat_late = 0;
+    // update() is pipelined like the 3-D map's (round 6): it returns once the frame's training is enqueued; the next update's
+    // first touch of the store, test(), gpis2_stats and gpis2_sync join it (the store joins by itself wherever it needs the models).
+    // GPIS_PIPELINE_UPDATE=0 / gpis2_set_pipeline(map, 0): every update() joins its own training (the reference's behaviour).  The
+    // 2-D clusters are small (K <= ~220 on data/2D: the fused kernel, 0.3 ms per frame), so no CUs are set aside for it.
+    bool pipeline = true;
+    int join_training() {
+        if (!store.train_pending()) return GPIS_OK;
+        const int rc = store.train_finish();
+        if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; rebuild_table(); }
+        return rc;
+    }
+    void rebuild_table();
 
     explicit Impl(const GPisMapParam& par)
         : tree(tree_param2()), store(2, par.map_scale_param),
           mq(2, (float)((double)par.map_scale_param * 4.0), 0.4f, (float)(1.0 + (double)par.map_noise_param)) {
         setting = par;      // assignment: the public struct's only copy constructor takes a non-const reference (as the reference's)
         ok = (hipGetDevice(&device) == hipSuccess) && (hipStreamCreate(&stream) == hipSuccess);
+        if (const char* e = getenv("GPIS_PIPELINE_UPDATE")) pipeline = atoi(e) != 0;
         if (!ok) device = -1;
         if (!ok) fprintf(stderr, "[gpismap_amd] GPisMap: no usable HIP device; update()/test() will fail\n");
     }
@@ -448,6 +461,7 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
         tree.query_clusters(tree.root, tree.nodes[a].c, (float)(4.0 * (double)tree.nodes[a].h), qs, nullptr);
         for (int c : qs) updateSet.insert(c);
     }
+    (void)join_training();      // the previous frame's batch, before any model slot is released or allocated
     for (int m : tree.released_models) store.release_slot(m);
     tree.released_models.clear();
     if (!updateSet.empty()) {  // (the reference divides by zero on an empty set, SURVEY B-5)
@@ -482,12 +496,17 @@ void GPisMap::Impl::updateGPs() {  // GPisMap.cpp:574-663 -> K6 + K3
                 soa[6 * np + i] = p.val; soa[7 * np + i] = p.sigx; soa[8 * np + i] = p.sigg;
             }
             int rc = store.upload_points(soa.data(), (int)np, stream);
+            store.defer_finish = pipeline;
             if (rc == GPIS_OK) rc = store.train_batch(jobs, ids, stream);
             if (rc != GPIS_OK) { fprintf(stderr, "[gpismap_amd] OnGPIS training failed (%d)\n", rc); if (!upd_rc) upd_rc = rc; }
             stat_clusters_trained += (long)jobs.size();
         }
     }
     activeSet.clear();
+    rebuild_table();
+}
+
+void GPisMap::Impl::rebuild_table() {
     std::vector<int> cl;
     tree.all_clusters(cl);
     std::vector<ClusterEntry> ent(cl.size());
@@ -562,6 +581,7 @@ bool GPisMap::testDevice(const float* d_x, int leng, float* d_res, void* hip_str
     if (!m.ok || !d_x || !d_res || leng < 1 || !m.has_tree) return false;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : m.stream;
     m.fail_rc = 0;
+    (void)m.join_training();
     const int rc = m.mq.run(m.store, d_x, leng, d_res, s);
     if (rc != GPIS_OK) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap::testDevice: device path failed (%d)\n", rc); }
     return rc == GPIS_OK;
@@ -576,6 +596,7 @@ bool GPisMap::test(float* x, int dim, int leng, float* res) try {  // GPisMap.cp
     if (!m.has_tree) return false;
     m.fail_rc = 0;
     auto fail = [&](int rc) { m.fail_rc = rc; fprintf(stderr, "[gpismap_amd] GPisMap::test: device path failed (%d)\n", rc); return false; };
+    (void)m.join_training();
     size_t nx = (size_t)2 * leng, nr = (size_t)6 * leng;
     if (nx > m.cap_x) { (void)hipFree(m.d_x); m.d_x = nullptr; m.cap_x = 0; if (hipMalloc(&m.d_x, sizeof(float) * nx) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_x = nx; }
     if (nr > m.cap_res) { (void)hipFree(m.d_res); m.d_res = nullptr; m.cap_res = 0; if (hipMalloc(&m.d_res, sizeof(float) * nr) != hipSuccess) return fail(GPIS_ERR_HIP); m.cap_res = nr; }
@@ -600,8 +621,21 @@ void GPisMap::getAllNodes(std::vector<float>& out) try {
     }
 } catch (const std::exception& e) { nothrow_report("GPisMap::getAllNodes", e.what()); } catch (...) { nothrow_report("GPisMap::getAllNodes", "unknown exception"); }
 
+int gpis2_impl_sync(GPisMap* g) {      // join the training the last update() left in flight; the update status
+    GPisMap::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    (void)m.join_training();
+    return m.upd_rc;
+}
+void gpis2_impl_set_pipeline(GPisMap* g, int on) {
+    GPisMap::Impl& m = *g->impl();
+    DeviceScope ds(m.device);
+    (void)m.join_training();
+    m.pipeline = on != 0;
+}
 void gpis2_impl_stats(GPisMap* g, double* out, int n) {
     GPisMap::Impl& m = *g->impl();
+    { DeviceScope ds(m.device); (void)m.join_training(); }      // (the training time of the last batch is read off its events)
     double v[12] = {(double)m.gpo.trained_groups(m.stream), (double)m.stat_obs_queries, (double)m.stat_clusters_trained,
                     (double)m.stat_late, (double)m.mq.num_clusters(), (double)m.mq.last_evals, (double)m.mq.last_eval_ms,
                     (double)m.store.device_bytes(), (double)m.mq.last_flops, (double)m.mq.last_launches,

@@ -169,6 +169,11 @@ int   gpis2_update(void* map, const float* thetas, const float* ranges, int n, c
 int   gpis2_test(void* map, const float* x, int dim, int n, float* res);
 int   gpis2_test_device(void* map, const float* d_x, int n, float* d_res, void* hip_stream);
 int   gpis2_device(void* map);
+/* Round 6: the 2-D update() is pipelined like the 3-D one -- it returns once the frame's OnGPIS training is enqueued; the next
+ * update, gpis2_test / _test_device, gpis2_stats and gpis2_sync join it (a failed training surfaces there).  gpis2_set_pipeline(map, 0)
+ * or GPIS_PIPELINE_UPDATE=0 restore the synchronous call.  Same map state and test() results in both modes. */
+int   gpis2_sync(void* map);
+int   gpis2_set_pipeline(void* map, int on);
 int   gpis2_get_nodes(void* map, float* out7, int cap);         /* pos2 grad2 val sigx sigg, tree order */
 int   gpis2_stats(void* map, double* out, int n);               /* same slots as gpis3_stats */
 

@@ -67,3 +67,24 @@ def test_2d_reset_gives_a_fresh_map():
         b.update(fr["thetas"], fr["ranges"], fr["pose"])
     assert np.array_equal(b.nodes(), na)
     assert np.array_equal(b.test(grid).view(np.uint32), ra.view(np.uint32))
+
+
+def test_2d_pipelined_update_equals_synchronous():
+    """Round 6: the 2-D update() is pipelined like the 3-D one (returns once its training is enqueued; test(), the next update,
+    stats and sync join it).  Same nodes and the same test() bits as the synchronous mode on the bundled sequence, with and
+    without a test() between the frames; gpis2_sync reports the joined training's status."""
+    import gpismap_amd
+    frames = replay.load_gazebo()[:8]
+    grid = replay.demo2_grid()[::5]
+    ref = gpismap_amd.GPisMap(); ref.set_pipeline(False)
+    a = gpismap_amd.GPisMap()                      # default: pipelined
+    b = gpismap_amd.GPisMap()
+    for i, fr in enumerate(frames):
+        ref.update(fr["thetas"], fr["ranges"], fr["pose"])
+        a.update(fr["thetas"], fr["ranges"], fr["pose"])
+        b.update(fr["thetas"], fr["ranges"], fr["pose"])
+        r = ref.test(grid)
+        assert np.array_equal(a.test(grid).view(np.uint32), r.view(np.uint32)), i      # test() after every update
+    b.sync()                                        # updates back to back, joined once
+    assert np.array_equal(b.nodes(), ref.nodes()) and np.array_equal(a.nodes(), ref.nodes())
+    assert np.array_equal(b.test(grid).view(np.uint32), ref.test(grid).view(np.uint32))

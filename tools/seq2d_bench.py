@@ -7,6 +7,8 @@ import numpy as np, gpismap_amd, replay
 frames = replay.load_gazebo(); grid = replay.demo2_grid()
 for rep in range(3):
     g2 = gpismap_amd.GPisMap()
+    if hasattr(g2, "set_pipeline") and hasattr(g2.L, "gpis2_set_pipeline"):
+        g2.set_pipeline(rep != 1)           # pass 2: synchronous update (the reference's split); passes 1, 3: the default (pipelined)
     up, te = [], []
     for fr in frames:
         t0 = time.perf_counter(); g2.update(fr["thetas"], fr["ranges"], fr["pose"]); up.append((time.perf_counter() - t0) * 1e3)
