@@ -6,17 +6,15 @@
 //        -> matern32_sparse_deriv1_3D (cross)  cpp/src/covFnc.cpp:258-314 (2-D: :404-450)
 //        -> k*^T alpha ; L^-1 k* ; column sums of squares
 //
-// The (1+d) cross-covariance columns of 8 queries form a K x 32 right-hand-side block B.  The reference solves L V = B by
-// substitution -- K dependent steps.  Here the factor's explicit inverse X = L^-1 comes out of training (K3b), so V = X B
-// (lower-triangular product, 32 x 32 tiles, v_mfma_f32_32x32x2_f32) has NO dependency between its block rows: every wavefront
-// owns a few block rows (accumulators in registers), streams their X tiles from L2 once and reads the B tiles all wavefronts
-// share from LDS.  alpha rides as row K of X: row K of V is the mean k*^T alpha (one ascending fmaf chain).
-//   * B is generated in chunks of CB column blocks into a THREE-slot LDS ring handed over through LDS counters: a wavefront
-//     multiplies chunk i once its tiles are counted in, then generates its tile of chunk i+2 (the duty goes round) once every
-//     wavefront is through with the slot's previous chunk.  No workgroup barrier in the loop (round 5: 15 % of the wave-cycles
-//     waited at the barrier that used to end every chunk).
-//   * block rows are dealt from the largest down, snake-wise (row b costs b+1 tile products); clusters with more than 4 W block
-//     rows run several row groups (B regenerated for the later, cheaper groups): no upper limit on K.
+// The (1+d) cross-covariance columns of 8 queries form a K x 32 block B.  The reference solves L V = B by substitution (K dependent
+// steps); here the factor's explicit inverse X = L^-1 comes out of training (K3b), so V = X B (32 x 32 tiles,
+// v_mfma_f32_32x32x2_f32) has NO dependency between its block rows: every wavefront owns a few block rows (accumulators in
+// registers), streams their X tiles from L2 once and reads the B tiles all wavefronts share from LDS.  alpha rides as row K of X.
+//   * B is generated in chunks of CB column blocks into a THREE-slot LDS ring handed over through LDS counters: a wavefront multiplies
+//     chunk i once its tiles are counted in, then generates its tile of chunk i+2 once every wavefront is through with the slot's
+//     previous chunk.  No workgroup barrier in the loop.  (Two and four slots: measured slower, NOTEBOOK R6.2.)
+//   * block rows are dealt from the largest down, snake-wise; clusters with more than 4 W block rows run several row groups (B
+//     regenerated for the later, cheaper groups): no upper limit on K.
 //   * every vector instruction of the generation stalls the SIMD's matrix pipe (profiles/r06_pivot_step.txt): the exponential is
 //     table-driven (exp_tab.h), sqrt and the three divisions of a gradient row are the range-restricted ones (tile_solve.h).
 //   * what lost and left this file (git history, NOTEBOOK R2-R6): the barrier kernel, exp tables in LDS and in global memory,
@@ -31,8 +29,7 @@
 
 namespace gpis {
 
-// Pointers read out of a ClusterModel live in global memory; say so, otherwise the compiler must
-// emit flat_load (LDS-or-global at run time), which counts on both wait counters.
+// Pointers read out of a ClusterModel live in global memory; say so (else: flat_load, which counts on both wait counters).
 typedef const float __attribute__((address_space(1))) * gfptr;
 typedef const int __attribute__((address_space(1))) * giptr;
 
@@ -57,10 +54,9 @@ constexpr int kTileStride = 36;     // floats per column of a B tile in LDS: con
 constexpr int kTileFloats = 32 * kTileStride;   // 1152
 static_assert(ONGPIS_TILE_Q == 8, "one set of 8 queries per workgroup (two sets at 256 VGPRs measured slower: NOTEBOOK R2, R5.8)");
 
-// Hand-overs of the ring through LDS counters (cumulative, never reset).  The counter is read through readfirstlane: a per-lane
-// loop condition would make everything after the loop divergent to the compiler (waterfall loops around the buffer loads,
-// wave-uniform values demoted to VGPRs).  The wait is bounded: a protocol error must not hang the queue -- the tile's results are
-// then written as NaN and the launch's error word is raised (MapQuery::run / eval_jobs return GPIS_ERR_STATE).
+// Hand-overs of the ring through LDS counters (cumulative, never reset), read through readfirstlane (a per-lane loop condition makes
+// everything behind the loop divergent to the compiler).  Bounded: a protocol error must not hang the queue -- the tile's results
+// are then NaN and the launch's error word is raised (MapQuery::run / eval_jobs return GPIS_ERR_STATE).
 typedef volatile int __attribute__((address_space(3))) * lds_cnt_t;
 __device__ __forceinline__ void k4_ring_wait(lds_cnt_t p, int need, lds_cnt_t expired, int limit) {
     int spins = 0;
@@ -85,13 +81,10 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
     constexpr int RG = NBW * W;   // block rows per row group
     constexpr int NSLOT = kSlots;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // Workgroup ids go round the eight XCDs (id b runs on XCD b % 8), and the tiles of ONE cluster are consecutive in the tile list:
-    // taken as they come, eight consecutive 8-query tiles land on eight different L2s and every one of them fetches the cluster's X
-    // from HBM for itself -- the stress configuration (64 queries = 8 tiles per cluster) read every model eight times.  Inside
-    // every block of 64 workgroup ids the (id / 8, id % 8) grid is transposed: XCD x takes the tiles 8x .. 8x + 7 of the block, so
-    // eight consecutive tiles share one L2 and run at about the same time; every XCD still takes every eighth group of eight
-    // (cutting the LIST into eight contiguous ranges instead was measured: stress +6 %, but the 256^3 bench 0.75 -> 0.63 of peak,
-    // the ranges of a launch differ by the K^2 of their clusters).  Which workgroup evaluates a tile does not enter any result.
+    // Workgroup ids go round the eight XCDs (id b on XCD b % 8) and the tiles of ONE cluster are consecutive in the list: taken as they
+    // come, eight consecutive tiles land on eight L2s and each fetches the cluster's X from HBM for itself.  Inside every block of 64
+    // ids the (id / 8, id % 8) grid is transposed: XCD x takes the tiles 8x .. 8x + 7, so eight consecutive tiles share one L2 (round 5:
+    // stress predict +5 %; contiguous ranges per XCD instead: bench 0.75 -> 0.63).  Which workgroup evaluates a tile enters no result.
     int tile = blockIdx.x;
     {
         const int n64 = (int)gridDim.x & ~63;
@@ -116,7 +109,6 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
     const int wait_limit = (A.debug & 16) ? (1 << 14) : (1 << 22);
     K4_TRACE_DECL(A)
     K4_STAMP();
-
     // LDS carve (all dynamic, 16-byte aligned pieces)
     constexpr int NC = 32;        // result columns of the workgroup
     float* red = reinterpret_cast<float*>(smem);                       // [W][NC] sums of squares, then [NC] means
@@ -127,10 +119,8 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
     float4* s_x4 = reinterpret_cast<float4*>(s_ri + ld);               // [N]   (ld is a multiple of 32 -> 16-B aligned)
     f64x2* s_exp = reinterpret_cast<f64x2*>(s_x4 + N);                 // [64] 2^(j/64) as (hi, lo): exp_tab.h
     float* Bbuf = reinterpret_cast<float*>(s_exp + 64);                // [NSLOT][CB][32*36]
-
     const float scale = mp->scale;
     const float a = (float)(sqrt(3.0) / (double)scale);
-
     {   // stage 0: per-cluster vectors and the queries into LDS with coalesced loads
         giptr g_ri = (giptr)mp->rowinfo;
         gfptr g_x4 = (gfptr)mp->x4;
@@ -148,14 +138,11 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
     const __amdgpu_buffer_rsrc_t Xrs = __builtin_amdgcn_make_buffer_rsrc((void*)mp->Xt, 0, (unsigned)ntl * 4096u, 0x00020000);
     const int Tvoff = lane * 16;
     K4_STAMP();
-
-    // ---- generation of one B tile (column block c) into an LDS tile: lane (r, qh) produces the 16 entries of tile row r for
-    // the queries 4qh..4qh+3 (distance, exponential and coefficient set-up shared by the 4 components).  KIND = row type of
-    // the whole tile when it is uniform (0: value rows, 1..3: d/dx_c rows -- the rows are ordered by type, so almost every tile
-    // is uniform and the type selects of covFnc.cpp:292-308 fold away), -1: mixed tile, per-row type.
-    // The tile is stored k-contiguous per column: element (row, n = 16 qh + 4 j + comp) -> tbuf[n * 36 + (row & 1) * 16 + (row >> 1)],
-    // i.e. Bt[n][h][kk] = B[2 kk + h][n]: the 16 operand values of a lane of the matrix instruction are FOUR 16-byte reads, and
-    // the 32 rows of a wavefront's store instruction fall into 32 different banks.
+    // ---- generation of one B tile (column block c) into an LDS tile: lane (r, qh) produces the 16 entries of tile row r for the
+    // queries 4qh..4qh+3.  KIND = row type of the whole tile when it is uniform (0: value rows, 1..3: d/dx_c rows -- rows are ordered
+    // by type, so almost every tile is uniform and the type selects of covFnc.cpp:292-308 fold away), -1: mixed tile.
+    // Stored k-contiguous per column: element (row, n = 16 qh + 4 j + comp) -> tbuf[n * 36 + (row & 1) * 16 + (row >> 1)], i.e.
+    // Bt[n][h][kk] = B[2 kk + h][n]: a lane's 16 operand values are FOUR 16-byte reads, a wavefront's stores hit 32 different banks.
     const int ngr = (dim > 0) ? (K - N) / dim : 0;   // rows per derivative component
     auto row_type = [&](int r) { return r < N ? 0 : 1 + (r - N) / (ngr > 0 ? ngr : 1); };
     auto emit_rows = [&](auto kind_tag, int c, float* tbuf) {
@@ -209,7 +196,6 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
         else if (k0 == 2) emit_rows(std::integral_constant<int, 2>(), c, tbuf);
         else emit_rows(std::integral_constant<int, 3>(), c, tbuf);
     };
-
     // ---- B chunks.  The chunks of all row groups form one sequence gci = 0, 1, ...; chunk gci lives in ring slot gci % 3.
     // Tile t of chunk p is made by wavefront (t + p CB) mod W: the duty goes round, every wavefront generates the same number of
     // tiles over a few chunks.  A slot is free once every wavefront has multiplied the chunk it held before.
@@ -241,18 +227,14 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
         ++pgci;
         if (++pci > cmax / CB) { pci = 0; ++pg; }
     };
-
     float ss = 0.f;               // partial sum of squares of V over this lane's rows (order O3, oracle reduce_ss)
     float mean_val = 0.f;         // row K of V (the lane that owns it)
     for (int i = 0; i < NSLOT - 1; ++i) produce_next();     // two chunks generated ahead of the multiplication
     K4_STAMP();
     int gci = 0;
     for (int g = 0; g < ngroups; ++g) {
-        // this wave's block rows in group g: slot t holds the (g RG + t W + q)-th largest row, q snaking with t
-        // (Round 5: pairing complementary rows q / 7 - q on the two wavefronts of a SIMD -- every SIMD then carries the same number
-        // of products in every chunk -- measured 0.7 % SLOWER on the bench and 4 points slower at K = 1598: a wavefront left alone on
-        // its SIMD with seven products does not hide its own X-tile loads.  The row table also fixes the order of the variance sums
-        // (oracle reduce_ss), so it is not free to change.  NOTEBOOK R5.2.)
+        // this wave's block rows in group g: slot t holds the (g RG + t W + q)-th largest row, q snaking with t.  (The row table also
+        // fixes the order of the variance sums -- oracle reduce_ss.  Pairing complementary rows on a SIMD's wavefronts: slower, R5.2.)
         int brow[NBW];
 #pragma unroll
         for (int t = 0; t < NBW; ++t) {
@@ -283,12 +265,9 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
                     const int b = brow[t];
                     if (b >= c0) {
                         const int cend = min(min(c0 + CB - 1, b), cmax);
-                        // ONE X-tile buffer used as a ring of four 16-byte pieces: as soon as the four matrix instructions
-                        // that read piece g have been issued, piece g of the NEXT tile of this block row is requested into
-                        // the same registers -- the next product's operands arrive under the current product (3/4 of a
-                        // product = 768 cycles ahead, about one L2 round trip) without a second buffer (two buffers: one
-                        // accumulator tile in scratch, NOTEBOOK R2).  The last tile of the row re-requests itself (clamped
-                        // address: branch-free, harmless).
+                        // ONE X-tile buffer used as a ring of four 16-byte pieces: once the four matrix instructions that read piece g
+                        // are issued, piece g of the NEXT tile of the row is requested into the same registers (768 cycles ahead, about
+                        // one L2 round trip) -- no second buffer.  The last tile of the row re-requests itself (clamped: branch-free).
                         float av1[16];
                         {
                             const int sbase = (b * (b + 1) / 2 + c0) * 4096;
@@ -326,12 +305,10 @@ __global__ __launch_bounds__(64 * W, kMinW) void ongpis_eval_kernel(EvalArgs A) 
             }
             if (mean_alone && g == 0 && wave == W - 1) {
                 // the mean of a cluster whose alpha sits alone in its block row: mean[n] = fmaf(alpha[k], B[k][n], mean[n]), k ascending
-                // through the column blocks of this chunk (group 0 meets every column block once, in order).  alpha[32 c + k] is element
-                // (row 0, column k) of tile (nbx - 1, c) in A-operand order: float (k >> 3) * 256 + (k & 1) * 128 + ((k >> 1) & 3) of
-                // the tile.  ONE gather load per pair of column blocks brings it into lanes 0..31 (block c) and 32..63 (block c + 1) --
-                // all requests of the chunk go out together, one round trip -- and the chain takes its operand by v_readlane (scalar
-                // loads, two per step: four dependent round trips per column block, the chain wavefront became the workgroup's tail).
-                // Lane n (both halves alike) reads column n of the B tile, k-contiguous.
+                // through this chunk's column blocks (group 0 meets every one once, in order).  alpha[32 c + k] = element (row 0, column k)
+                // of tile (nbx - 1, c) in A-operand order: float (k >> 3) * 256 + (k & 1) * 128 + ((k >> 1) & 3).  ONE gather load per pair
+                // of column blocks (lanes 0..31 block c, 32..63 block c + 1), operands by v_readlane (scalar loads: four dependent round
+                // trips per block made this wavefront the workgroup's tail).  Lane n reads column n of the B tile, k-contiguous.
                 const float* buf = Bbuf + (size_t)(gci % NSLOT) * CB * kTileFloats;
                 const int c0 = ci * CB, cl = min(c0 + CB - 1, cmax);
                 const int avoff = (lane >> 5) * 4096 + ((l31 >> 3) * 1024 + (l31 & 1) * 512 + ((l31 >> 1) & 3) * 4);
@@ -427,21 +404,17 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     if (wclass < 0 || wclass >= ONGPIS_NCLASS) return GPIS_ERR_ARG;
     EvalArgs args = args_in;
 #ifdef GPIS_EXPERIMENTS   // the archived resident-X kernel for clusters of at most ONGPIS_SMALL_NBX block rows (tools/experiments/)
-    if (getenv("GPIS_SMALL_KERNEL") && atoi(getenv("GPIS_SMALL_KERNEL")) && wclass <= 2 && maxLd / 32 <= ONGPIS_SMALL_NBX && ongpis_eval_small_lds(maxN, maxLd) <= (size_t)160 * 1024)
-        return ongpis_eval_small_launch(ntiles, maxN, maxLd, args_in, s);
+    if (getenv("GPIS_SMALL_KERNEL") && atoi(getenv("GPIS_SMALL_KERNEL")) && wclass <= 2 && maxLd / 32 <= ONGPIS_SMALL_NBX && ongpis_eval_small_lds(maxN, maxLd) <= (size_t)160 * 1024) return ongpis_eval_small_launch(ntiles, maxN, maxLd, args_in, s);
 #endif
     const int W = kClassW[wclass];
-    // LDS budget: the register file admits kWavesPerCU wavefronts per CU, i.e. kWavesPerCU / W workgroups; give each an
-    // equal share of the 160 KB and spend what the per-cluster tables leave on the ring of B chunks: three slots of
-    // cb column blocks (cb <= 8).  What the ring wants is WIDE chunks: three slots of five column blocks 0.772-0.775 of peak,
-    // three slots of three beside an exp table in LDS 0.751, two slots of five with a barrier per chunk (rounds 2-4) 0.748-0.753.
+    // LDS budget: the register file admits kWavesPerCU / W workgroups per CU; each gets an equal share of the 160 KB and spends what
+    // the per-cluster tables leave on the ring: three slots of cb column blocks (cb <= 8; wide chunks beat more slots, NOTEBOOK R6.2).
     const size_t hard = 158 * 1024;
     const size_t share = std::min(hard, hard * W / kWavesPerCU);
     const size_t blk = sizeof(float) * kTileFloats;    // one column block
     const size_t fixed = eval_lds_fixed(W, maxN, maxLd);
     if (fixed + kSlots * blk > hard) return GPIS_ERR_LIMIT;
-    // (the small classes keep their occupancy: chunks of at least two / three column blocks at the price of fewer workgroups per CU
-    // measured 35 -> 30 / 24 % at K = 204, 17 -> 13 / 9 % at K = 102)
+    // (the small classes keep their occupancy: wider chunks at the price of fewer workgroups per CU measured 35 -> 30 % at K = 204)
     const size_t budget = std::min(hard, std::max(share, fixed + kSlots * blk));
     const int nblk = (int)((budget - fixed) / blk);           // column blocks the ring can hold
     int cb = std::max(1, std::min(nblk / kSlots, 8));
@@ -460,19 +433,14 @@ int ongpis_eval_launch(int wclass, int ntiles, int maxN, int maxLd, const EvalAr
     k4_trace_dump(s, W, 0, ntiles, maxN, maxLd, cb);
 #endif
     const hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-        fprintf(stderr, "[gpismap_amd] K4 launch failed: %s (class %d, %d waves, %d tiles, LDS %zu B, cb %d)\n",
-                hipGetErrorString(le), wclass, W, ntiles, lds, cb);
-        return GPIS_ERR_HIP;
-    }
+    if (le != hipSuccess) { fprintf(stderr, "[gpismap_amd] K4 launch failed: %s (class %d, %d waves, %d tiles, LDS %zu B, cb %d)\n", hipGetErrorString(le), wclass, W, ntiles, lds, cb); return GPIS_ERR_HIP; }
     return GPIS_OK;
 }
 
 int ongpis_eval_class(int nbx) { return ongpis_class_of_nbx(nbx); }
 
-// Can K4 hold a cluster of N points / leading dimension ld?  It stages the row table and the points in LDS beside a
-// three-slot ring of at least one column block each.  Asked at TRAINING time: a cluster that could be factorised but
-// never evaluated is refused there (GPIS_ERR_LIMIT, the previous model is kept).
+// Can K4 hold a cluster (row table + points in LDS beside a three-slot ring of one column block each)?  Asked at TRAINING time: a
+// cluster that could be factorised but never evaluated is refused there (GPIS_ERR_LIMIT, the previous model is kept).
 bool ongpis_eval_fits(int N, int ld) {
     const int W = kClassW[ongpis_class_of_nbx(ld / 32)];
     return eval_lds_fixed(W, N, ld) + kSlots * sizeof(float) * kTileFloats <= (size_t)158 * 1024;

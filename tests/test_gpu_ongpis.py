@@ -130,6 +130,27 @@ def test_size_class_boundaries(n):
     assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
 
 
+@pytest.mark.parametrize("dim,scale,n", [(3, 0.04, 8), (3, 0.04, 16), (3, 0.04, 24), (2, 1.2, 32), (2, 1.2, 64), (2, 1.2, 96)])
+def test_lone_mean_row_in_the_small_classes_and_in_2d(dim, scale, n):
+    """K a multiple of 32 in the one- and two-wavefront classes of K4 (K = 32, 64, 96) and in 2-D (K = 3 N = 96, 192, 288): alpha sits
+    alone in the last block row of the stored inverse, the mean is the vector-ALU chain of round 6 and the variance sums deal
+    K / 32 block rows -- bit-identical to the oracle, full and partial query tiles."""
+    import gpismap_amd
+    rng = np.random.default_rng(4000 + 10 * dim + n)
+    pos, grad, val, sx, sg = make_cluster(rng, dim, n, scale, frac_nograd=0.0)
+    st = gpismap_amd.OnGPIS(dim, scale, keep_factor=True)
+    models = st.train(soa9(dim, pos, grad, val, sx, sg), np.array([0, n], dtype=np.int32), np.arange(n, dtype=np.int32))
+    g = st.model(models[0])
+    assert g["K"] == (1 + dim) * n and g["K"] % 32 == 0
+    nq = 19
+    xq = (pos[rng.integers(0, n, nq)] + rng.normal(0, 0.3 * scale, (nq, dim))).astype(np.float32)
+    ref = oracle_lib.ongpis_predict(dim, scale, pos, grad, val, sx, sg, xq)
+    out = st.eval(xq, np.arange(nq, dtype=np.int32), np.full(nq, models[0], dtype=np.int32))
+    nc = 1 + dim
+    got = np.concatenate([out[:, :nc], out[:, 4:4 + nc]], axis=1)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+
+
 def test_predict_without_exp_table_is_identical():
     """Clusters too large for the per-tile exp table in LDS take a path that evaluates exp() per kernel
     entry (gpis_ongpis_set_exp_table(0) forces it): results must not change by a bit."""
