@@ -84,6 +84,7 @@ void pool_destroy(DevPool*);
 void* pool_alloc(DevPool*, size_t bytes);
 void pool_free(DevPool*, void* p);
 size_t pool_bytes(DevPool*);
+size_t pool_block_size(DevPool*, void* p);   // bytes of a live block of the pool (0: none)
 size_t pool_cache_trim();   // hand the process-wide cache of pool chunks back to the driver; returns the bytes released
 
 }  // namespace gpis

@@ -200,6 +200,11 @@ void pool_free(DevPool* p, void* ptr) {
     p->add_free(a, sz);
 }
 size_t pool_bytes(DevPool* p) { return p->bytes; }
+size_t pool_block_size(DevPool* p, void* ptr) {      // bytes of a live block (0: not one)
+    if (!ptr) return 0;
+    auto it = p->live_.find(ptr);
+    return it == p->live_.end() ? 0 : it->second;
+}
 
 // ------------------------------------------------------------ ObsGPDevice ----
 static constexpr int OVERLAP2 = 3, GROUP2 = 5;   // params.h:108-109

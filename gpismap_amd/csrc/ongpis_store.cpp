@@ -184,7 +184,16 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
     int ld = (int)align_up((size_t)K + 1, 32);
     int nbk = ld / 32;   // block rows incl. the one holding the y row (the factorisation uses those tiles as operands)
     const size_t szT = sizeof(float) * 1024 * (size_t)nbk * (nbk + 1) / 2;
-    free_model_mem(m);
+    // Round 6: a model that is retrained at (about) its old size keeps its blocks -- a frame retrains ~500 models and most of them
+    // grew by a few points or not at all; every one used to go through two frees and two best-fit searches of the pool.  A block is
+    // kept when it holds the new size with at most a quarter to spare (everything in it is rewritten by the training kernels).
+    char* keep_base = nullptr; char* keep_sc = nullptr;
+    auto take = [&](void*& blk, size_t need) -> char* {
+        const size_t have = pool_block_size(pool_, blk);
+        if (have < need || have > need + need / 4 + (64u << 10)) return nullptr;
+        char* b = (char*)blk; blk = nullptr; return b;
+    };
+    auto alloc_or = [&](char* kept, size_t need) -> char* { return kept ? kept : (char*)pool_alloc(pool_, need); };
     if (kind == kAllocPredictOnly || kind == kAllocLeanFactor) {
         // what K4 reads (rowinfo, x4, Xt): imported models and models trained by the fused on-chip kernel;
         // kAllocLeanFactor adds the factor, alpha and the gradient index for parity tests / gpis_ongpis_get_model
@@ -197,7 +206,9 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
             oL = total; oA = align_up(oL + sizeof(float) * (size_t)ld * ld, 256); oG = align_up(oA + sizeof(float) * ld, 256);
             total = align_up(oG + sizeof(int) * (size_t)N, 256);
         }
-        char* base = (char*)pool_alloc(pool_, total);
+        { void* b = m.base; keep_base = take(b, total); m.base = (char*)b; }
+        free_model_mem(m);
+        char* base = alloc_or(keep_base, total);
         if (!base) return GPIS_ERR_HIP;
         std::memset(&m, 0, sizeof(ClusterModel));
         m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
@@ -218,6 +229,7 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
         size_t oT = align_up(oA + szA, 256);
         size_t oZt = align_up(oT + szT, 256);
         const size_t total_s = align_up(oZt + szT, 256);
+        free_model_mem(m);
         char* base = (char*)pool_alloc(pool_, total_p);
         if (!base) return GPIS_ERR_HIP;
         char* sc = (char*)pool_alloc(pool_, total_s);
@@ -244,9 +256,12 @@ int OnGPISStore::alloc_model(int slot, int N, int ng, int kind) {
     size_t oT = align_up(oG + szG, 256);
     size_t oZt = align_up(oT + szT, 256);                   // transposed tiles of the inverse (K3b's B operands)
     const size_t total_s = align_up(oZt + szT, 256);
-    char* base = (char*)pool_alloc(pool_, total_p);
-    if (!base) return GPIS_ERR_HIP;
-    char* sc = (char*)pool_alloc(pool_, total_s);
+    { void* b = m.base; keep_base = take(b, total_p); m.base = (char*)b; }
+    { void* b = m.scratch; keep_sc = take(b, total_s); m.scratch = (char*)b; }
+    free_model_mem(m);
+    char* base = alloc_or(keep_base, total_p);
+    if (!base) { if (keep_sc) pool_free(pool_, keep_sc); return GPIS_ERR_HIP; }
+    char* sc = alloc_or(keep_sc, total_s);
     if (!sc) { pool_free(pool_, base); return GPIS_ERR_HIP; }
     std::memset(&m, 0, sizeof(ClusterModel));
     m.dim = dim_; m.N = N; m.ng = ng; m.K = K; m.ld = ld; m.nb = (K + 31) / 32; m.scale = scale_;
