@@ -684,6 +684,9 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
 
     // replay in the reference's order; node lists are fetched lazily per cluster (:308-311)
     std::vector<int>& nodes = ws_nodes; std::vector<int>& late = ws_late;
+#ifdef GPIS_INSTRUMENT
+    float late_ms = 0.f; int late_batches = 0;
+#endif
     for (int c : sel) {
         nodes.clear();
         tree.all_points(c, nodes);
@@ -691,7 +694,15 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
         for (int pid : nodes) if (pid >= (int)slot.size() || slot[pid] < 0) late.push_back(pid);
         std::vector<Stage2> lst;
         std::vector<float> lval, lvar;
-        if (!late.empty()) { reeval_batch(late, lst, lval, lvar); stat_late += (long)late.size(); }
+        if (!late.empty()) {
+#ifdef GPIS_INSTRUMENT
+            auto t0 = std::chrono::steady_clock::now();
+#endif
+            reeval_batch(late, lst, lval, lvar); stat_late += (long)late.size();
+#ifdef GPIS_INSTRUMENT
+            late_ms += std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++late_batches;
+#endif
+        }
         size_t li = 0;
         for (int pid : nodes) {
             if (pid < (int)slot.size() && slot[pid] >= 0) {
@@ -703,6 +714,9 @@ void GPisMap3::Impl::updateMapPoints() {  // GPisMap3.cpp:258-319
         }
     }
     ulap("reEvalPoints: apply");
+#ifdef GPIS_INSTRUMENT
+    fprintf(stderr, "[upd] late re-evaluations: %d batches, %.2f ms of the apply lap\n", late_batches, late_ms);
+#endif
 }
 
 // ------------------------------------------------------------------ evalPoints ----

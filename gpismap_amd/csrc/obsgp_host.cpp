@@ -3,10 +3,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <condition_variable>
 #include <mutex>
 #include <set>
-#include <thread>
 #include <vector>
 #include <algorithm>
 #include "obsgp.h"
@@ -36,7 +34,7 @@ struct DevPool {
     void add_free(char* a, size_t sz) { free_addr_[a] = sz; free_size_.insert({sz, a}); }
 };
 // Standard-size chunks of destroyed pools are kept per device for the next pool of the process (a 512 MiB hipMalloc
-// costs milliseconds -- a map that is reset / re-created per sequence paid for its whole pool again, in the middle of its
+// costs 15 ms whenever the driver has to wipe the pages first -- a map that is reset / re-created per sequence paid for its whole pool again, in the middle of its
 // first frames); bounded by GPIS_POOL_CACHE_GB (default 16, 0 = give everything back at once; a 4 GB default was measured in round 5: the
 // F = 5 bench map holds 7 GB of models, and every fusion after the first paid 3 x 5 ms of hipMalloc in its last frame again).  gpis_pool_cache_trim() (C-ABI,
 // also run at process exit by the Python mirror) hands the cached chunks back to the driver; a hipMalloc of the library that
@@ -49,62 +47,12 @@ size_t chunk_cache_limit() {
     static const size_t lim = [] { const char* e = getenv("GPIS_POOL_CACHE_GB"); const double gb = e ? atof(e) : 16.0; return (size_t)(gb > 0 ? gb * 1024.0 * 1024.0 * 1024.0 / (double)kPoolChunk : 0); }();
     return lim;
 }
-// Round 6: the pool grows OFF the caller's thread.  A 512 MiB hipMalloc costs 5-10 ms, and a fresh process paid it inside the
-// update() calls that grew the map (profiles/r05_update_pipeline.txt, first repeat: frames of 40-58 ms where a warm process
-// takes 17).  A helper thread keeps spare chunks in the per-device cache ahead of the demand: as soon as a pool of a device
-// takes its first chunk, the helper allocates until the cache holds max(8, as many as the device's pools hold) chunks -- a growing
-// map takes three or four chunks per frame, one hipMalloc takes as long as a frame: the reserve is built while the demand is low
-// (bounded by GPIS_POOL_CACHE_GB like the cache itself), and tops it up whenever a pool takes one.  A pool that finds the cache
-// empty still allocates for itself, as before.  gpis_pool_cache_trim() parks the helper until the next pool grows;
-// GPIS_POOL_PREFETCH=0 turns it off.  The helper never touches a stream: hipMalloc on its own thread.
-struct ChunkPrefetch {
-    std::thread th;
-    std::condition_variable cv, idle_cv;
-    bool started = false, stop = false, busy = false;
-    std::map<int, bool> active;          // device -> a pool grew since the last trim
-    std::map<int, size_t> handed;        // device -> standard chunks held by live pools
-};
-ChunkPrefetch g_pf;
-bool prefetch_enabled() {
-    static const bool on = [] { const char* e = getenv("GPIS_POOL_PREFETCH"); return !(e && atoi(e) == 0) && chunk_cache_limit() > 0; }();
-    return on;
-}
-size_t prefetch_target(int dev) {      // (g_chunk_mu held)
-    if (!g_pf.active[dev]) return 0;
-    return std::min(chunk_cache_limit(), std::max((size_t)8, g_pf.handed[dev]));
-}
-void prefetch_main() {
-    std::unique_lock<std::mutex> lk(g_chunk_mu);
-    for (;;) {
-        int dev = -1;
-        for (auto& kv : g_pf.active)
-            if (kv.second && g_chunk_cache[kv.first].size() < prefetch_target(kv.first)) { dev = kv.first; break; }
-        if (g_pf.stop) break;
-        if (dev < 0) { g_pf.busy = false; g_pf.idle_cv.notify_all(); g_pf.cv.wait(lk); continue; }
-        g_pf.busy = true;
-        lk.unlock();
-        void* c = nullptr;
-        const bool ok = hipSetDevice(dev) == hipSuccess && hipMalloc(&c, kPoolChunk) == hipSuccess;
-        if (!ok) (void)hipGetLastError();
-        lk.lock();
-        if (ok) g_chunk_cache[dev].push_back(c);
-        else g_pf.active[dev] = false;      // (out of memory or no device: the pools fend for themselves)
-    }
-    g_pf.busy = false;
-    g_pf.idle_cv.notify_all();
-}
-void prefetch_kick(int dev) {             // (g_chunk_mu held) a pool of `dev` took or needed a chunk
-    if (!prefetch_enabled() || dev < 0) return;
-    g_pf.active[dev] = true;
-    if (!g_pf.started) { g_pf.started = true; g_pf.stop = false; g_pf.th = std::thread(prefetch_main); }
-    g_pf.cv.notify_one();
-}
-struct PrefetchJoin {                     // the helper is joined before the process' static state goes away
-    ~PrefetchJoin() {
-        { std::lock_guard<std::mutex> lk(g_chunk_mu); g_pf.stop = true; g_pf.cv.notify_all(); }
-        if (g_pf.th.joinable()) g_pf.th.join();
-    }
-} g_pf_join;
+// Round 6, measured (tools/ubench/malloc_busy.hip, profiles/r06_malloc_busy.txt): a 512 MiB hipMalloc costs 0.02 ms while the driver
+// still has wiped pages to hand out and 15.1 ms (the wipe of 512 MiB) once it has not -- whichever thread asks, with or without
+// kernels in flight.  A helper thread that kept max(8, as many as the pools hold) spare chunks ahead of the demand was built on
+// the round-5 reading ("5-10 ms per chunk") and removed again: it doubled the process' demand, ran into the 15 ms allocations the
+// pools alone never met, and those stalled update() by 30-220 ms a frame (the wipes share the copy engines with its small
+// transfers).  The pools allocate for themselves, exactly what they need.
 void* chunk_cache_take() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -112,13 +60,10 @@ void* chunk_cache_take() {
     void* c = nullptr;
     auto it = g_chunk_cache.find(dev);
     if (it != g_chunk_cache.end() && !it->second.empty()) { c = it->second.back(); it->second.pop_back(); }
-    ++g_pf.handed[dev];                   // (the caller allocates for itself when the cache is empty: a chunk is handed either way)
-    prefetch_kick(dev);
     return c;
 }
 bool chunk_cache_put(int dev, void* c) {
     std::lock_guard<std::mutex> lk(g_chunk_mu);
-    if (g_pf.handed[dev] > 0) --g_pf.handed[dev];
     auto& v = g_chunk_cache[dev];
     if (v.size() >= chunk_cache_limit()) return false;
     v.push_back(c);
@@ -128,9 +73,7 @@ bool chunk_cache_put(int dev, void* c) {
 size_t pool_cache_trim() {
     std::vector<std::pair<int, void*>> all;
     {
-        std::unique_lock<std::mutex> lk(g_chunk_mu);
-        for (auto& kv : g_pf.active) kv.second = false;            // park the helper, and wait for an allocation in flight
-        g_pf.idle_cv.wait(lk, [] { return !g_pf.busy; });
+        std::lock_guard<std::mutex> lk(g_chunk_mu);
         for (auto& kv : g_chunk_cache) { for (void* c : kv.second) all.push_back({kv.first, c}); kv.second.clear(); }
     }
     for (auto& dc : all) { DeviceScope ds(dc.first); (void)hipFree(dc.second); }
@@ -139,9 +82,6 @@ size_t pool_cache_trim() {
 DevPool* pool_create() {
     DevPool* p = new DevPool();
     if (hipGetDevice(&p->device) != hipSuccess) p->device = -1;
-    // (the helper starts filling the device's chunk cache now: a map's first training, tens of milliseconds after its
-    // construction, already finds chunks there)
-    { std::lock_guard<std::mutex> lk(g_chunk_mu); prefetch_kick(p->device); }
     return p;
 }
 void pool_destroy(DevPool* p) {
