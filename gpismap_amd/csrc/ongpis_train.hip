@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void ongpis_buildK_kernel(const ClusterModel* 
 // All loads are unconditional (the padding rows are part of the allocation) and issued before the chain that consumes
 // them; only the arithmetic is predicated on the row being < K.  y lives in LDS (`ybuf`, ycap floats) when it fits.
 template <int NTH>
-__device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf, int ycap, float* av, int tid, int lane, int wave) {
+__device__ __forceinline__ void chol_epilogue_barrier(const ClusterModel& m, float* ybuf, int ycap, float* av, int tid, int lane, int wave) {
     const int K = m.K, ld = m.ld, nb = m.nb;
     float* L = m.L;
     float* yv = (K <= ycap) ? ybuf : m.y;
@@ -278,6 +278,164 @@ __device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf
         }
         __syncthreads();
     }
+    // restore the identity in row K so the padded square is a valid triangular factor
+    for (int jj = tid; jj < K; jj += NTH) L[K + (size_t)jj * ld] = 0.f;
+    if (tid == 0) L[K + (size_t)K * ld] = 1.f;
+    // K4 runs over whole 32-row blocks without row predicates: the padding rows K..32nb-1 must stay exactly
+    // zero through its solve, so alpha is zero there and row K (the y row) is cleared in the re-tiled copy too.
+    for (int jj = K + tid; jj < ld; jj += NTH) m.alpha[jj] = 0.f;
+    if (K % 32 != 0) {
+        const int pr = K - 32 * (nb - 1);
+        for (int idx = tid; idx < (nb - 1) * 8; idx += NTH) {
+            const int c = idx >> 3, g = (idx >> 1) & 3, hh = idx & 1;
+            float4* t = reinterpret_cast<float4*>(m.Lt + (size_t)tri_index(nb - 1, c) * 1024);
+            t[g * 64 + hh * 32 + pr] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
+// The same back substitution WITHOUT workgroup barriers (round 6): with two barriers per block column the 32-step triangle of
+// wave 0, the load round trip of the row update and the barriers themselves followed one another -- 12 k cycles per block column,
+// 0.19 ms of a 1.10 ms K = 1190 factorisation (tools/k3_bench.py with the epilogue compiled out).  Here wave 0 only solves
+// triangles; the rows of y (all in LDS) belong to the other wavefronts by PAIRS of blocks (pair p = blocks 2p, 2p + 1 on the two
+// lane halves of updater p mod NU), every updater walks the steps c = nb-1 .. 1 and applies block c to its pairs below c, the
+// pair that holds block c-1 first -- its L tile is requested BEFORE alpha_c is known -- and reports it (LDS word); wave 0 starts
+// triangle c-1 as soon as that report is in, while the updaters finish the other rows of step c.  alpha_c is published in place
+// of y_c.  A row still takes the blocks in descending order from ONE lane (program order): the chains are those of the barrier
+// version, bit for bit.  Waits are bounded; an expired one poisons alpha with NaN (a protocol error must not pass for a result).
+typedef volatile int __attribute__((address_space(3))) * epi_word_t;
+// (the factor through GLOBAL pointers: a flat load counts on the LDS wait counter too, and every poll of a progress word would wait
+// for the tile requests in flight -- the look-ahead would be gone)
+typedef const f32x4 __attribute__((address_space(1))) * epi_gvec_t;
+typedef float __attribute__((address_space(1))) * epi_gf_t;
+__device__ __forceinline__ void epi_wait_le(epi_word_t p, int need, epi_word_t expired) {
+    int spins = 0;
+    constexpr int kLimit = 1 << 22;
+    for (; spins < kLimit; ++spins) {
+        if (__builtin_amdgcn_readfirstlane(*p) <= need) break;
+        if ((spins & 1023) == 1023 && __builtin_amdgcn_readfirstlane(*expired) != 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    if (spins == kLimit) *expired = 1;
+    __asm__ volatile("" ::: "memory");      // (everything handed over lives in LDS, which a wavefront accesses in order: a compiler barrier is the
+                                            // whole acquire -- a workgroup-scope fence would also wait for the tile requests in flight, vmcnt(0))
+}
+__device__ __forceinline__ void epi_publish(epi_word_t p, int value, int lane) {
+    __asm__ volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xc07f);                       // this wavefront's LDS stores are complete
+    if (lane == 0) *p = value;
+    __asm__ volatile("" ::: "memory");
+}
+
+template <int NTH>
+__device__ __forceinline__ void chol_epilogue(const ClusterModel& m, float* ybuf, int ycap, float* av, int tid, int lane, int wave) {
+    constexpr int NWV = NTH / 64;
+    if (NWV < 3 || m.K > ycap) { chol_epilogue_barrier<NTH>(m, ybuf, ycap, av, tid, lane, wave); return; }   // (one wavefront: nothing to overlap; y beyond the LDS buffer: K > 9216)
+    constexpr int NU = NWV - 1;                // updaters
+    const int K = m.K, ld = m.ld, nb = m.nb;
+    float* L = m.L;
+    float* yv = ybuf;
+    epi_word_t w = (epi_word_t)av;             // [0] alpha published down to this block, [1] y complete down to this block, [2] a wait expired
+    for (int jj = tid; jj < 32 * nb; jj += NTH) yv[jj] = (jj < K) ? ((gfptr_t)L)[K + (size_t)jj * ld] : 0.f;
+    if (tid == 0) { w[0] = nb; w[1] = nb - 1; w[2] = 0; }
+    __syncthreads();
+    const int l31 = lane & 31, h = lane >> 5;
+    if (wave == 0) {
+        float4 dq[8], dqn[8];
+        float dg = 1.f, dgn = 1.f;
+        auto load_diag_block = [&](float4 (&q)[8], float& g, int c) {
+            const int cr = 32 * c;
+            epi_gvec_t cp = (epi_gvec_t)(L + (size_t)cr + (size_t)(cr + l31) * ld);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const f32x4 t = cp[i]; q[i] = make_float4(t[0], t[1], t[2], t[3]); }
+            g = ((gfptr_t)L)[(size_t)(cr + l31) * (ld + 1)];
+        };
+        load_diag_block(dq, dg, nb - 1);
+        for (int c = nb - 1; c >= 0; --c) {
+            const int cr = 32 * c;
+            if (c > 0) load_diag_block(dqn, dgn, c - 1);      // in flight during the wait and the triangle
+            epi_wait_le(w + 1, c, w + 2);
+            float dcol[32];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { dcol[4 * q] = dq[q].x; dcol[4 * q + 1] = dq[q].y; dcol[4 * q + 2] = dq[q].z; dcol[4 * q + 3] = dq[q].w; }
+            float b = yv[cr + l31];                            // (rows >= K of the last block were staged as zero)
+            const float dd = (cr + l31 < K) ? dg : 1.f;
+            const float ddr = rcp_refined(dd);
+            const int kv = K - cr;
+#pragma unroll
+            for (int k = 31; k >= 0; --k) {
+                const float t = div_ranged(b, dd, ddr);
+                const float ak = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(t), k));
+                const float nb_ = (l31 == k) ? ak : ((l31 < k) ? fmaf(-dcol[k], ak, b) : b);
+                b = (k < kv) ? nb_ : b;
+            }
+            if (lane < 32) {
+                yv[cr + lane] = (cr + lane < K) ? b : 0.f;     // alpha_c replaces y_c
+                if (cr + lane < K) ((epi_gf_t)m.alpha)[cr + lane] = b;
+            }
+            epi_publish(w + 0, c, lane);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) dq[q] = dqn[q];
+            dg = dgn;
+        }
+    } else {
+        const int u = wave - 1;
+        auto load_cols = [&](float4 (&q)[8], int p, int cr) {      // rows cr .. cr+31 of the lane's column of pair p (contiguous in the column-major factor)
+            const int jj = 32 * (2 * p + h) + l31;
+            epi_gvec_t cp = (epi_gvec_t)(L + (size_t)cr + (size_t)jj * ld);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const f32x4 t = cp[i]; q[i] = make_float4(t[0], t[1], t[2], t[3]); }
+        };
+        for (int c = nb - 1; c >= 1; --c) {
+            const int cr = 32 * c;
+            const int ptop = (c - 1) >> 1;                          // the pair that holds block c-1
+            int p = ptop - ((ptop - u) % NU + NU) % NU;             // this updater's highest pair at this step
+            if (p < 0) continue;
+            float4 cq[8], cn[8];
+            load_cols(cq, p, cr);                                   // requested before alpha_c exists
+            epi_wait_le(w + 0, c, w + 2);
+            float a[32];
+            {
+                const float4* ap = reinterpret_cast<const float4*>(yv + cr);
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const float4 t = ap[q]; a[4 * q] = t.x; a[4 * q + 1] = t.y; a[4 * q + 2] = t.z; a[4 * q + 3] = t.w; }
+            }
+            const int kv = K - cr;                                   // < 32 only for the last block
+            for (; p >= 0; p -= NU) {
+                const int pn = p - NU;
+                if (pn >= 0) load_cols(cn, pn, cr);
+                const int bl = 2 * p + h;
+                const int jj = 32 * bl + l31;
+                if (bl < c) {
+                    float s = yv[jj];
+                    if (kv >= 32) {
+#pragma unroll
+                        for (int q = 7; q >= 0; --q) {
+                            s = fmaf(-cq[q].w, a[4 * q + 3], s);
+                            s = fmaf(-cq[q].z, a[4 * q + 2], s);
+                            s = fmaf(-cq[q].y, a[4 * q + 1], s);
+                            s = fmaf(-cq[q].x, a[4 * q], s);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 7; q >= 0; --q) {
+                            if (4 * q + 3 < kv) s = fmaf(-cq[q].w, a[4 * q + 3], s);
+                            if (4 * q + 2 < kv) s = fmaf(-cq[q].z, a[4 * q + 2], s);
+                            if (4 * q + 1 < kv) s = fmaf(-cq[q].y, a[4 * q + 1], s);
+                            if (4 * q < kv) s = fmaf(-cq[q].x, a[4 * q], s);
+                        }
+                    }
+                    yv[jj] = s;
+                }
+                if (p == ptop) epi_publish(w + 1, c - 1, lane);     // y of block c-1 is complete: its triangle may start
+#pragma unroll
+                for (int q = 0; q < 8; ++q) cq[q] = cn[q];
+            }
+        }
+    }
+    __syncthreads();
+    const bool failed = w[2] != 0;
+    if (failed) for (int jj = tid; jj < K; jj += NTH) m.alpha[jj] = __uint_as_float(0x7fc00000u);
     // restore the identity in row K so the padded square is a valid triangular factor
     for (int jj = tid; jj < K; jj += NTH) L[K + (size_t)jj * ld] = 0.f;
     if (tid == 0) L[K + (size_t)K * ld] = 1.f;
