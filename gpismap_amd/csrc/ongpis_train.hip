@@ -21,6 +21,12 @@ namespace gpis {
 
 typedef const float __attribute__((address_space(1))) * gfptr_t;
 
+#ifdef GPIS_INSTRUMENT
+#include "ongpis_coop_instr.inc"
+#else
+#define CSTAMP(i) do {} while (0)
+#endif
+
 #define JOB_MODEL(j) d_jobs[4 * (j) + 0]
 #define JOB_OFF(j) d_jobs[4 * (j) + 1]
 #define JOB_N(j) d_jobs[4 * (j) + 2]
@@ -768,22 +774,34 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
 
     // The tiles of one block row bi of column j: chain (needs row j's off-diagonal tiles), then -- once L_jj is there -- the
     // solve, the stores and the incremental diagonal update.
+    // The products of a chain, operands two deep: the loads of product p + 1 are in flight while product p multiplies.  Straight-line
+    // trips (a tile index clamped to the last one instead of a branch around the loads: the last tile is simply requested again) with
+    // the order pinned -- with the loads inside `if (p + 1 < j)` the wait counts at the joins were conservative, and the sign flips of
+    // the NEXT tile's operand (vector instructions on freshly requested registers) were scheduled in front of the CURRENT product:
+    // every product waited for the loads issued just before it (coop trace: 0.65 us per product for 0.43 us of matrix instructions).
     auto chain = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
         if (j > 0) {
-            float a_[2][16], bq[2][16];
-            load_tile(a_[0], j, 0); load_tile(bq[0], bi, 0);
+            float a0[16], b0[16], a1[16], b1[16];
+            load_tile(a0, j, 0); load_tile(b0, bi, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll 1
             for (int p = 0; p < j; p += 2) {
-                if (p + 1 < j) { load_tile(a_[1], j, p + 1); load_tile(bq[1], bi, p + 1); }
+                const int p1 = min(p + 1, j - 1);
+                load_tile(a1, j, p1); load_tile(b1, bi, p1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[0][kk], bq[0][kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[kk], b0[kk], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                const int p2 = min(p + 2, j - 1);
+                load_tile(a0, j, p2); load_tile(b0, bi, p2);
+                __builtin_amdgcn_sched_barrier(0);
                 if (p + 1 < j) {
-                    if (p + 2 < j) { load_tile(a_[0], j, p + 2); load_tile(bq[0], bi, p + 2); }
 #pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a_[1][kk], bq[1][kk], acc, 0, 0, 0);
+                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[kk], b1[kk], acc, 0, 0, 0);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     };
@@ -846,6 +864,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     for (int j = 0; j < nb; ++j) {
         const int pw = min(32, K - 32 * j);
         const bool owner = (j % G == g);
+        CSTAMP(0);
         const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
         if (!owner && first >= nbr) continue;                       // nothing left for this workgroup in later columns either
         const int bi0 = first + wave * G, bi1 = bi0 + NW * G;       // the two look-ahead rows of this wavefront
@@ -854,6 +873,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its write-through tile stores of the previous steps have left
             __syncthreads();           // this workgroup's stores of the previous steps (tiles of row j, its diagonal updates)
             publish(rowtiles, j + 1);
+            CSTAMP(1);
             if (wave != 0) {
                 if (bi0 < nbr) chain(acc0, bi0, j);
                 if (bi1 < nbr) chain(acc1, bi1, j);
@@ -926,6 +946,7 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 }
                 if (!(inject && j == 1)) publish(rowready, j + 1);
             }
+            CSTAMP(3);
             __syncthreads();           // L_jj in Lc for this workgroup's own solves; the other wavefronts' chains are accumulated
             if (wave == 0) {
                 // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it).  After
@@ -939,12 +960,15 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
                 if (bi0 < nbr) chain(acc0, bi0, j);
                 if (bi1 < nbr) chain(acc1, bi1, j);
+                CSTAMP(2);
             }
             if (first >= nbr) continue;
         } else {
             if (!wait_flag(rowtiles, j + 1)) return;      // expired / aborted: error word set, the cluster is abandoned
+            CSTAMP(1);
             if (bi0 < nbr) chain(acc0, bi0, j);
             if (bi1 < nbr) chain(acc1, bi1, j);
+            CSTAMP(2);
             if (!wait_flag(rowready, j + 1)) return;
             // non-owners copy the published (padded) diagonal factor
             if (tid < 256) {
@@ -952,14 +976,17 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
                 reinterpret_cast<float4*>(Lc)[tid] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
             }
             __syncthreads();
+            CSTAMP(3);
         }
         if (bi0 < nbr) finish(acc0, bi0, j);
+        CSTAMP(4);
         if (bi1 < nbr) finish(acc1, bi1, j);
         for (int bi = bi1 + NW * G; bi < nbr; bi += NW * G) {     // (more than two rows per wavefront: the rest without look-ahead)
             f32x16 acc;
             chain(acc, bi, j);
             finish(acc, bi, j);
         }
+        CSTAMP(6);
     }
     // ---- all rows done: workgroup 0 runs the back-substitution over the complete factor
     __syncthreads();
@@ -1261,6 +1288,9 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
 #endif
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
     if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync, d_ctl);
+#ifdef GPIS_INSTRUMENT
+    if (nwg > 0 && getenv("GPIS_COOP_TRACE")) coop_trace_dump(s, nwg);
+#endif
 }
 // workgroups of the cooperative kernel that can be resident at once on the current device (its waits need every workgroup
 // of a cluster running): CUs x occupancy, less a sixteenth as a margin for the kernels of the other size groups
