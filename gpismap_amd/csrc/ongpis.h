@@ -166,6 +166,7 @@ private:
     int train_allocated(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
     int train_enqueue(const std::vector<TrainJob>& jobs, const std::vector<int>* ids, hipStream_t s, int deferred_rc);
     int coop_dev_ = 0, coop_held_ = 0;           // cooperative workgroups this store holds of its device's budget (batch in flight)
+    std::vector<int> coop_hdr_;                  // host copy of the cooperative clusters' header words (kept: the upload is asynchronous)
     bool enqueued_ = false;                      // train_enqueue() got as far as handing the batch to train_finish()
     int* d_rg_ = nullptr; int cap_rg_ = 0;       // range gather: cell point lists, cell entries, cluster descriptors, counts
     int dev_ids_ = 0;                            // ids the last gather_ranges() left in d_ids_
@@ -226,6 +227,8 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
 void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
+// the same clusters as a data flow over per-row progress words (ongpis_train.hip): d_sync[3 j + 2] = offset of cluster j's 2 x rows flag words
+void ongpis_launch_chol_flow(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
 int ongpis_coop_capacity();
 // A stream for training kernels: reserve_cus == 0: non-blocking, lowest priority; reserve_cus > 0: restricted to the first
 // (CUs - reserve_cus) bits of the CU mask (such a stream is a DEFAULT-flag, normal-priority stream: HIP offers no masked creator

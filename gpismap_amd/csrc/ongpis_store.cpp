@@ -618,6 +618,8 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         if (n0 <= avail / 4) { kCoopMinNb = 16; kCoopGDiv = 225; kCoopGMax = 16; }
         else if (n0 <= avail / 2) { kCoopGDiv = 450; kCoopGMax = 8; }
     }
+    // (first cut: the data-flow kernel behind a switch)
+    const bool coop_flow = [] { const char* e = getenv("GPIS_K3_FLOW"); return e && atoi(e) != 0; }();
     int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
 #include "ongpis_store_instr.inc"   // schedule knobs from the environment (tuning sweeps only)
@@ -633,7 +635,8 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         for (int j = 0; j < n0; ++j) {
             const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
             if (nbj < kCoopMinNb) break;
-            const int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
+            int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
+            if (coop_flow) G = std::min(16, std::max(G, (nbj + 3) / 4));     // two wavefronts per block row where the device has room
             if (total + G > kCoopMaxWG) break;
             int x = 0;
             for (int i = 1; i < 8; ++i) if (sub[i].size() < sub[x].size()) x = i;
@@ -686,7 +689,16 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         cap_work_ = cap;
     }
     if (ncoop > 0) {
-        const size_t need = cwork.size() + 3 * (size_t)ncoop;
+        // behind the work list: three words per cooperative cluster (ready / done / tiles -- or, for the data-flow kernel, abort /
+        // done / offset of its flag words), then 2 x rows progress words per cluster; everything but the offsets starts at zero
+        coop_hdr_.assign(3 * (size_t)ncoop, 0);
+        size_t flags = 0;
+        for (int j = 0; j < ncoop; ++j) {
+            const int Kj = tab[4 * j + 2] + dim_ * tab[4 * j + 3];
+            coop_hdr_[3 * (size_t)j + 2] = coop_flow ? (int)(3 * (size_t)ncoop + flags) : 0;
+            if (coop_flow) flags += 2 * (size_t)((Kj + 32) / 32);
+        }
+        const size_t need = cwork.size() + 3 * (size_t)ncoop + flags;
         if ((int)need > cap_cwork_) {
             (void)hipFree(d_cwork_); d_cwork_ = nullptr;
             int cap = (int)need * 2 + 1024;
@@ -694,7 +706,8 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
             cap_cwork_ = cap;
         }
         GPIS_HIP(hipMemcpyAsync(d_cwork_, cwork.data(), sizeof(int) * cwork.size(), hipMemcpyHostToDevice, s));
-        GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * 3 * (size_t)ncoop, s));
+        GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * (3 * (size_t)ncoop + flags), s));
+        if (coop_flow) GPIS_HIP(hipMemcpyAsync(d_cwork_ + cwork.size(), coop_hdr_.data(), sizeof(int) * coop_hdr_.size(), hipMemcpyHostToDevice, s));
     }
     if (ids) GPIS_HIP(hipMemcpyAsync(d_ids_, ids->data(), sizeof(int) * ids->size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
@@ -749,7 +762,10 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         if (grp > 0) GPIS_HIP(hipStreamWaitEvent(gs[grp], evf_, 0));
         ongpis_launch_gather(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_ids_, pts_.d, pts_.cap, gs[grp]);
         ongpis_launch_buildK(d_models_, d_jobs_ + 4 * nbeg, ncnt, gs[grp]);
-        if (grp == 0) ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
+        if (grp == 0) {
+            if (coop_flow) ongpis_launch_chol_flow(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
+            else ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
+        }
 #ifdef GPIS_EXPERIMENTS
         else if (grp == 1 && getenv("GPIS_ASYNC_CHOL") && atoi(getenv("GPIS_ASYNC_CHOL"))) ongpis_launch_chol_async(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_err_, gs[grp]);
 #endif

@@ -1000,6 +1000,284 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterM
     chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
 }
 
+// ---------------------------------------------------------------------------
+// K3 for a FEW large clusters (round 6): the cooperative factorisation as a data flow, no workgroup barriers in the sweep.
+// The trace of the kernel above (profiles/r06_k3_coop_trace.txt) shows every wavefront busy, not waiting: the tiles of a block row
+// are one chain after the other in ONE wavefront per column (0.6 us per product + 3.7 us solve / store / diagonal update), so a
+// cluster of 38 block rows cannot finish before ~0.55 ms whatever G is.  Here block row r belongs to TWO wavefronts, one for the
+// even and one for the odd columns: while tile (r, j) waits for its last operands and is solved, the other wavefront already
+// accumulates tile (r, j + 1) as far as its operands exist.  Progress is per ROW: prog[r] = number of leading tiles of row r that
+// are final, diag[r] = L_rr is in its Zt slot.  A product p of tile (r, j) needs prog[j] > p and prog[r] > p; the solve needs
+// diag[j]; the wavefront that finishes tile (r, r - 1) holds the completed diagonal block and factorises it at once.  Tiles are
+// stored write-through and announced after vmcnt(0) (as above); a tile is never read before it is final, the diagonal blocks
+// travel through device-scope loads: no cache maintenance.  Every element keeps its chain: bit-identical to the kernels above.
+// Waits are bounded (ctl[2] ticks): error word bit 1 + abort mark, as above.  The G workgroups of a cluster are resident together
+// (one per CU, launch <= capacity); wavefront v = 8 g + w takes the tasks (row, parity) t = v, v + 8 G, ... of 2 (rows - 1).
+// flags = sync + sync[3 job + 2]: [0 .. rows) prog, [rows .. 2 rows) diag; sync[3 job] < 0 = abort, sync[3 job + 1] = workgroups done.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void ongpis_chol_flow_kernel(const ClusterModel* __restrict__ models,
+                                                                const int* __restrict__ d_jobs, const int* __restrict__ cwork,
+                                                                int* __restrict__ sync, int* __restrict__ ctl) {
+    constexpr int NW = 8;
+    __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];      // per wavefront: tile transpose buffer (and the workspace of a partial pivot block)
+    __shared__ __attribute__((aligned(16))) float LcW[NW][32 * 32];     // per wavefront: the diagonal factor it solves with
+    __shared__ float av[32];
+    __shared__ int abort_s;
+    const int job = cwork[3 * blockIdx.x], g = cwork[3 * blockIdx.x + 1], G = cwork[3 * blockIdx.x + 2];
+    if (job < 0) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const ClusterModel& m = models[JOB_MODEL(job)];
+    const int K = m.K, ld = m.ld, nb = m.nb;
+    float* L = m.L;
+    const int nbr = ld / 32;
+    const int ntl = nbr * (nbr + 1) / 2;
+    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
+    const int Tvoff = lane * 16;
+    const int Lvoff = (l31 + 4 * h * ld) * 4;
+    auto tile_soff = [&](int bi, int jc, int r) { return (unsigned)((bi * 32 + (size_t)(jc * 32 + (r & 3) + 8 * (r >> 2)) * ld) * 4); };
+    int* state = sync + 3 * job;          // < 0: a wavefront of this cluster gave up
+    int* alldone = sync + 3 * job + 1;
+    int* prog = sync + sync[3 * job + 2];
+    int* diag = prog + nbr;
+    const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
+    const bool inject = (ctl[1] & 1) != 0;
+    float* T = Tt[wave];
+    float* Lc = LcW[wave];
+    auto load_tile = [&](float (&o)[16], int b, int c) {
+        const int sbase = tri_index(b, c) * 4096;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + gg * 1024, 0);
+            o[4 * gg + 0] = __uint_as_float(q[0]); o[4 * gg + 1] = __uint_as_float(q[1]);
+            o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
+        }
+    };
+    // one lane polls; the value seen (>= v) or -1 (expired / a partner gave up) comes back wave-uniform
+    auto wait_ge = [&](int* f, int v) -> int {
+        int seen = 0;
+        if (lane == 0) {
+            const long long t0 = wall_clock64();
+            for (;;) {
+                seen = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (seen >= v) break;
+                if (__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) { seen = -1; break; }
+                if (wall_clock64() - t0 > wait_ticks) {
+                    seen = -1;
+                    atomicOr(ctl, 2);
+                    __hip_atomic_store(state, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        __asm__ volatile("" ::: "memory");
+        return seen;
+    };
+    auto publish = [&](int* f, int v) {       // this wavefront's write-through stores have left; then the counter moves
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // L_rr from the accumulated diagonal block t (lane = row, 16 of the 32 columns per lane half): factor into Lc (padded,
+    // column-major), column-major factor and Zt slot to memory, hand-over, then inv(L_rr) into the diagonal slot of Lt
+    auto pivot = [&](f32x16& t, int r) __attribute__((always_inline)) {
+        const int pw = min(32, K - 32 * r);
+        if (pw == 32) {
+            factor32_mb<0>(t, l31, h, lane, Lc);
+            factor32_mb<1>(t, l31, h, lane, Lc);
+            factor32_mb<2>(t, l31, h, lane, Lc);
+            factor32_mb<3>(t, l31, h, lane, Lc);
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Lc[c * 32 + lane]), Lrs, lane * 4, (unsigned)((r * 32 + (size_t)(r * 32 + c) * ld) * 4), 0);
+            }
+        } else {
+            float* D = T;      // (32 x 33 floats fit the 32 x 36 transpose buffer, which is idle here)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) D[l31 * 33 + rowmap_t(q, h)] = t[q];
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;
+            for (int c = 0; c < pw; ++c) {
+                float d = sqrtf(Dv[c * 33 + c]);
+                float lij = 0.f;
+                const bool below = (lane > c && lane < 32);
+                if (below) lij = Dv[lane * 33 + c] / d;
+                if (lane == c) Dv[c * 33 + c] = d;
+                if (below) Dv[lane * 33 + c] = lij;
+                if (below) {
+                    const float nl = -lij;
+                    const int kend = min(lane, pw - 1);
+                    for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 32) {
+                for (int c = 0; c < 32; ++c) {
+                    float v = Dv[lane * 33 + c];
+                    Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
+                    if (c < pw && c <= lane) L[(size_t)(r * 32 + lane) + (size_t)(r * 32 + c) * ld] = v;
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        {
+            const int zbase = tri_index(r, r) * 4096;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const float4 q = reinterpret_cast<const float4*>(Lc)[gg * 64 + lane];
+                u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(qu, Zrs, Tvoff, zbase + gg * 1024, 16);
+            }
+        }
+        if (!(inject && r == 1)) publish(diag + r, 1);
+        f32x16 x;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) x[q] = (rowmap_t(q, h) == l31) ? 1.f : 0.f;
+        diag_solve32<true>(x, Lc, h);
+        float* Dt = m.Lt + (size_t)tri_index(r, r) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
+#pragma unroll
+        for (int q = 0; q < 16; ++q) Dt[rowmap_t(q, h) * 4] = x[q];
+    };
+
+    const int v = g * NW + wave, V = G * NW;
+    const int ntask = 2 * (nbr - 1);
+    int have_diag = -1;                   // the pivot row whose factor sits in this wavefront's Lc
+    bool ok = true;
+    if (v == 0) {                         // row 0 has no tiles: its diagonal block is the kernel matrix's, factorised before tile (1, 0)
+        f32x16 t;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(0, 0, q), 0));
+        pivot(t, 0);
+        have_diag = 0;
+    }
+    for (int j = 0; j < nb && ok; ++j) {
+        for (int t = v; t < ntask && ok; t += V) {
+            const int r = (t >> 1) + 1;
+            if ((t & 1) != (j & 1) || r <= j) continue;
+            // ---- tile (r, j): T = A(r, j) - sum_{p < j} L(r, p) L(j, p)^T, products as far as both rows have got
+            f32x16 acc;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(r, j, q), 0));
+            int p = 0;
+            while (p < j) {
+                const int sj = wait_ge(prog + j, p + 1);
+                if (sj < 0) { ok = false; break; }
+                const int sr = wait_ge(prog + r, p + 1);
+                if (sr < 0) { ok = false; break; }
+                const int pe = min(j, min(sj, sr));       // products p .. pe - 1 have their operands
+                float a0[16], b0[16], a1[16], b1[16];
+                load_tile(a0, j, p); load_tile(b0, r, p);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+                for (; p < pe; p += 2) {
+                    const int p1 = min(p + 1, pe - 1);
+                    load_tile(a1, j, p1); load_tile(b1, r, p1);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[kk], b0[kk], acc, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int p2 = min(p + 2, pe - 1);
+                    load_tile(a0, j, p2); load_tile(b0, r, p2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (p + 1 < pe) {
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[kk], b1[kk], acc, 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                p = pe;
+            }
+            if (!ok) break;
+            // ---- L_jj
+            if (have_diag != j) {
+                if (wait_ge(diag + j, 1) < 0) { ok = false; break; }
+#pragma unroll
+                for (int gg = 0; gg < 4; ++gg) {
+                    auto q = __builtin_amdgcn_raw_buffer_load_b128(Zrs, Tvoff, tri_index(j, j) * 4096 + gg * 1024, 16);
+                    reinterpret_cast<float4*>(Lc)[gg * 64 + lane] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                have_diag = j;
+            }
+            // ---- solve, stores, diagonal update (the chain's operations of the kernel above)
+            diag_solve32<true>(acc, Lc, h);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[q]), Lrs, Lvoff, tile_soff(r, j, q), 0);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) T[l31 * 36 + rowmap_t(q, h)] = -acc[q];   // Lt holds -L
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            float tq[16];
+            const int tbase = tri_index(r, j) * 4096;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                float4 q;
+                q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
+                q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
+                q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
+                q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
+                u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
+                __builtin_amdgcn_raw_buffer_store_b128(qu, Trs, Tvoff, tbase + gg * 1024, 16);
+                tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (r < nb) {          // A(r, r) -= L(r, j) L(r, j)^T: the other wavefront of the row wrote it last (announced with prog[r] = j)
+                f32x16 dacc;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) dacc[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(r, r, q), 16));
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
+                if (j == r - 1) {
+                    publish(prog + r, j + 1);
+                    pivot(dacc, r);          // the row is complete: its pivot block at once
+                    have_diag = r;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[q]), Lrs, Lvoff, tile_soff(r, r, q), 16);
+                    publish(prog + r, j + 1);
+                }
+            } else publish(prog + r, j + 1);
+        }
+    }
+    // ---- all rows done: workgroup 0 runs the back-substitution over the complete factor
+    if (tid == 0) abort_s = 0;
+    __syncthreads();
+    if (!ok && lane == 0) abort_s = 1;
+    __syncthreads();
+    if (abort_s) return;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(alldone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (g != 0) return;
+    if (tid == 0) {
+        const long long t0 = wall_clock64();
+        int okd = 1;
+        for (;;) {
+            if (__hip_atomic_load(alldone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) break;
+            if (__hip_atomic_load(state, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) { okd = 0; break; }
+            if (wall_clock64() - t0 > wait_ticks) { okd = 0; atomicOr(ctl, 2); __hip_atomic_store(state, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        abort_s = !okd;
+    }
+    __syncthreads();
+    if (abort_s) return;
+    chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
+}
+
 #ifdef GPIS_EXPERIMENTS
 #include "../../tools/experiments/ongpis_chol_async.inc"   // barrier-free one-workgroup factorisation (measured equal on the frames)
 #endif
@@ -1294,6 +1572,9 @@ void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, co
 }
 // workgroups of the cooperative kernel that can be resident at once on the current device (its waits need every workgroup
 // of a cluster running): CUs x occupancy, less a sixteenth as a margin for the kernels of the other size groups
+void ongpis_launch_chol_flow(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
+    if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_flow_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync, d_ctl);
+}
 int ongpis_coop_capacity() {
     int dev = 0, ncu = 0;
     if (hipGetDevice(&dev) != hipSuccess) return 0;
