@@ -2,6 +2,7 @@
 // the 2-D tiling, :85-143 for the 1-D groups), buffer management, H2D/D2H.
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <set>
@@ -102,6 +103,12 @@ void* pool_alloc(DevPool* p, size_t bytes) {
     if (it == p->free_size_.end()) {
         const size_t chunk = std::max(c, kChunk);
         void* base = (chunk == kChunk) ? chunk_cache_take() : nullptr;
+#ifdef GPIS_INSTRUMENT
+        struct SlowAlloc {      // (instrumented builds: an allocation the driver had to wipe pages for shows up as ~15 ms per 512 MiB)
+            std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(); bool mine;
+            ~SlowAlloc() { const float ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); if (mine && ms > 1.f) fprintf(stderr, "[pool] hipMalloc of a chunk took %.1f ms\n", ms); }
+        } slow_alloc{std::chrono::steady_clock::now(), base == nullptr};
+#endif
         if (!base && hipMalloc(&base, chunk) != hipSuccess) {
             (void)hipGetLastError();
             if (pool_cache_trim() == 0 || hipMalloc(&base, chunk) != hipSuccess) { (void)hipGetLastError(); return nullptr; }

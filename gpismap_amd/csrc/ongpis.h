@@ -226,8 +226,7 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
 // K3 for the largest clusters: G cooperating workgroups each; cwork = (job, g, G) per workgroup (job < 0: padding), sync = 3 ints per job (zeroed)
 // d_ctl: 4 ints -- [0] error word of the batch (bit 0 fused kernel refused a job, bit 1 cooperative wait expired, bit 2 K3b row
 // wait expired), [1] test-only fault injection, [2] wait bound in ticks of the 100 MHz device clock (0: 2 s)
-void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
-// the same clusters as a data flow over per-row progress words (ongpis_train.hip): d_sync[3 j + 2] = offset of cluster j's 2 x rows flag words
+// the cooperative clusters (data flow over per-row progress words, ongpis_train.hip): d_sync[3 j + 2] = offset of cluster j's 2 x rows flag words
 void ongpis_launch_chol_flow(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s);
 int ongpis_coop_capacity();
 // A stream for training kernels: reserve_cus == 0: non-blocking, lowest priority; reserve_cus > 0: restricted to the first

@@ -618,8 +618,6 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         if (n0 <= avail / 4) { kCoopMinNb = 16; kCoopGDiv = 225; kCoopGMax = 16; }
         else if (n0 <= avail / 2) { kCoopGDiv = 450; kCoopGMax = 8; }
     }
-    // (first cut: the data-flow kernel behind a switch)
-    const bool coop_flow = [] { const char* e = getenv("GPIS_K3_FLOW"); return e && atoi(e) != 0; }();
     int kLongCol = 24;   // K3b: columns with more block rows than this take a workgroup of 8 pipelined wavefronts
 #ifdef GPIS_INSTRUMENT
 #include "ongpis_store_instr.inc"   // schedule knobs from the environment (tuning sweeps only)
@@ -632,17 +630,33 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         // (workgroup ids go round-robin over the XCDs), padded with job = -1 entries whose workgroups exit at once
         std::vector<int> sub[8];
         int total = 0;
+        // first the schedule's G per cluster, as far as the budget of resident workgroups goes ...
+        std::vector<int> Gs;
         for (int j = 0; j < n0; ++j) {
             const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
             if (nbj < kCoopMinNb) break;
-            int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
-            if (coop_flow) G = std::min(16, std::max(G, (nbj + 3) / 4));     // two wavefronts per block row where the device has room
+            const int G = std::min(kCoopGMax, std::max(2, (nbj * nbj + kCoopGDiv / 2) / kCoopGDiv));
             if (total + G > kCoopMaxWG) break;
+            Gs.push_back(G);
+            total += G;
+        }
+        // ... then, in a batch that leaves the device room (the latency regimes above), what is left of the budget goes to the
+        // largest clusters until each block row has its two wavefronts (8 G >= 2 rows: tools/k3_bench.py, one K = 1190 cluster
+        // 0.84 ms with G = 6, 0.78 with 10; K = 680 0.44 / 0.36)
+        if (kCoopGDiv < 900) {
+            for (size_t j = 0; j < Gs.size() && total < kCoopMaxWG; ++j) {
+                const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
+                const int want = std::min(16, std::max(Gs[j], (nbj + 3) / 4));
+                const int add = std::min(want - Gs[j], kCoopMaxWG - total);
+                Gs[j] += add; total += add;
+            }
+        }
+        for (size_t j = 0; j < Gs.size(); ++j) {
+            const int G = Gs[j];
             int x = 0;
             for (int i = 1; i < 8; ++i) if (sub[i].size() < sub[x].size()) x = i;
-            for (int g = 0; g < G; ++g) { sub[x].push_back(j); sub[x].push_back(g); sub[x].push_back(G); }
-            total += G;
-            ncoop = j + 1;
+            for (int g = 0; g < G; ++g) { sub[x].push_back((int)j); sub[x].push_back(g); sub[x].push_back(G); }
+            ncoop = (int)j + 1;
         }
         coop_give_back(coop_dev, coop_share - total);   // keep what the launch needs until the batch is joined
         coop_dev_ = coop_dev; coop_held_ = total;
@@ -689,14 +703,14 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         cap_work_ = cap;
     }
     if (ncoop > 0) {
-        // behind the work list: three words per cooperative cluster (ready / done / tiles -- or, for the data-flow kernel, abort /
-        // done / offset of its flag words), then 2 x rows progress words per cluster; everything but the offsets starts at zero
+        // behind the work list: three words per cooperative cluster (abort / workgroups done / offset of its flag words), then
+        // 2 x rows progress words per cluster; everything but the offsets starts at zero
         coop_hdr_.assign(3 * (size_t)ncoop, 0);
         size_t flags = 0;
         for (int j = 0; j < ncoop; ++j) {
             const int Kj = tab[4 * j + 2] + dim_ * tab[4 * j + 3];
-            coop_hdr_[3 * (size_t)j + 2] = coop_flow ? (int)(3 * (size_t)ncoop + flags) : 0;
-            if (coop_flow) flags += 2 * (size_t)((Kj + 32) / 32);
+            coop_hdr_[3 * (size_t)j + 2] = (int)(3 * (size_t)ncoop + flags);
+            flags += 2 * (size_t)((Kj + 32) / 32);
         }
         const size_t need = cwork.size() + 3 * (size_t)ncoop + flags;
         if ((int)need > cap_cwork_) {
@@ -707,7 +721,7 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         }
         GPIS_HIP(hipMemcpyAsync(d_cwork_, cwork.data(), sizeof(int) * cwork.size(), hipMemcpyHostToDevice, s));
         GPIS_HIP(hipMemsetAsync(d_cwork_ + cwork.size(), 0, sizeof(int) * (3 * (size_t)ncoop + flags), s));
-        if (coop_flow) GPIS_HIP(hipMemcpyAsync(d_cwork_ + cwork.size(), coop_hdr_.data(), sizeof(int) * coop_hdr_.size(), hipMemcpyHostToDevice, s));
+        GPIS_HIP(hipMemcpyAsync(d_cwork_ + cwork.size(), coop_hdr_.data(), sizeof(int) * coop_hdr_.size(), hipMemcpyHostToDevice, s));
     }
     if (ids) GPIS_HIP(hipMemcpyAsync(d_ids_, ids->data(), sizeof(int) * ids->size(), hipMemcpyHostToDevice, s));
     GPIS_HIP(hipMemcpyAsync(d_jobs_, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, s));
@@ -762,10 +776,7 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         if (grp > 0) GPIS_HIP(hipStreamWaitEvent(gs[grp], evf_, 0));
         ongpis_launch_gather(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_ids_, pts_.d, pts_.cap, gs[grp]);
         ongpis_launch_buildK(d_models_, d_jobs_ + 4 * nbeg, ncnt, gs[grp]);
-        if (grp == 0) {
-            if (coop_flow) ongpis_launch_chol_flow(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
-            else ongpis_launch_chol_coop(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
-        }
+        if (grp == 0) ongpis_launch_chol_flow(d_models_, d_jobs_, d_cwork_, (int)cwork.size() / 3, d_cwork_ + cwork.size(), d_err_, gs[0]);
 #ifdef GPIS_EXPERIMENTS
         else if (grp == 1 && getenv("GPIS_ASYNC_CHOL") && atoi(getenv("GPIS_ASYNC_CHOL"))) ongpis_launch_chol_async(d_models_, d_jobs_ + 4 * nbeg, ncnt, d_err_, gs[grp]);
 #endif

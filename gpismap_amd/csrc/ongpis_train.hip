@@ -21,12 +21,6 @@ namespace gpis {
 
 typedef const float __attribute__((address_space(1))) * gfptr_t;
 
-#ifdef GPIS_INSTRUMENT
-#include "ongpis_coop_instr.inc"
-#else
-#define CSTAMP(i) do {} while (0)
-#endif
-
 #define JOB_MODEL(j) d_jobs[4 * (j) + 0]
 #define JOB_OFF(j) d_jobs[4 * (j) + 1]
 #define JOB_N(j) d_jobs[4 * (j) + 2]
@@ -680,340 +674,29 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : (NW == 4 ? 2 : K3_T
 
 
 // ---------------------------------------------------------------------------
-// K3 for the LARGEST clusters: G cooperating workgroups per cluster (one per CU).  A single workgroup needs ~15 ms for a
-// K = 2300 factorisation (74 dependent block columns on one CU) while the rest of the chip idles.  Here block ROW bi of
-// the factor belongs to workgroup bi mod G, the sweep is still left-looking and every element keeps its ascending-(p, k)
-// fmaf chain (bit-identical to the single-workgroup kernel):
-//   step j, owner of row j:   the diagonal block L(j,j) is already fully accumulated (see below) -> factor it in registers,
-//                             write L_jj and its inverse, publish "row j ready" (release fence + device-scope flag);
-//   step j, every workgroup:  acquire row j, then for each owned row bi > j (dealt to the 8 wavefronts)
-//                                 T = A(bi,j) - sum_{p<j} L(bi,p) L(j,p)^T     own row (local) x row j (remote, just acquired)
-//                                 L(bi,j) = T L_jj^-T ; store column-major + re-tiled
-//                                 A(bi,bi) -= L(bi,j) L(bi,j)^T                 incremental diagonal: when step bi arrives the
-//                                                                               diagonal block only needs the factorisation
-// One flag hand-over per block column (row j's owner -> everybody); visibility follows the gfx950 recipe (plain stores,
-// workgroup barrier, one lane: agent-scope release + vmcnt(0) + relaxed device-scope flag store; consumer: one lane polls,
-// agent-scope acquire, workgroup barrier, plain loads of tiles nobody on this CU has touched before).  The launch holds
-// at most one workgroup per CU (<= 240 in total), so every workgroup of a cluster becomes resident and the waits end.
-// The blocked back-substitution for alpha runs on workgroup 0 of the cluster after all rows are done.
-// ---------------------------------------------------------------------------
-// Every wait is bounded by the device's constant 100 MHz clock (ctl[2] ticks, default 2 s -- a cooperative cluster takes
-// milliseconds): on expiry the waiting workgroup ORs bit 1 into the error word ctl[0], raises the cluster's abort flag so
-// that its partners stop too, and leaves; the host reads the word after the batch and reports GPIS_ERR_STATE (the batch
-// is not usable).  ctl[1] bit 0 is test-only fault injection: the owner of block row 1 "forgets" to publish it.
-__global__ __launch_bounds__(512, 2) void ongpis_chol_coop_kernel(const ClusterModel* __restrict__ models,
-                                                                const int* __restrict__ d_jobs, const int* __restrict__ cwork,
-                                                                int* __restrict__ sync, int* __restrict__ ctl) {
-    constexpr int NW = 8;
-    __shared__ int abort_s[2];     // (two words used alternately: a wait may follow the previous one before every wavefront has read its verdict)
-    __shared__ __attribute__((aligned(16))) float D[32 * 33];
-    __shared__ __attribute__((aligned(16))) float Lc[32 * 32];
-    __shared__ __attribute__((aligned(16))) float Tt[NW][32 * 36];
-    __shared__ float av[32];
-    const int job = cwork[3 * blockIdx.x], g = cwork[3 * blockIdx.x + 1], G = cwork[3 * blockIdx.x + 2];   // (XCD-aware order, job < 0: padding -- ongpis_store.cpp)
-    if (job < 0) return;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = lane >> 5, l31 = lane & 31;
-    const ClusterModel& m = models[JOB_MODEL(job)];   // (a reference: the fields come through scalar loads; a by-value copy sits in ~35 VGPRs and is spilled)
-    const int K = m.K, ld = m.ld, nb = m.nb;
-    float* L = m.L;
-    const int nbr = ld / 32;
-    const int ntl = nbr * (nbr + 1) / 2;
-    const __amdgpu_buffer_rsrc_t Trs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Lt, 0, (unsigned)ntl * 4096u, 0x00020000);
-    const int Tvoff = lane * 16;
-    int* rowready = sync + 3 * job;      // number of leading block rows whose tiles and diagonal factor are complete (0 initially);
-                                         // negative: a workgroup of this cluster gave up (abort)
-    int* alldone = sync + 3 * job + 1;   // workgroups that have finished their rows
-    int* rowtiles = sync + 3 * job + 2;  // number of leading block rows whose OFF-diagonal tiles are complete (their owner is about to factor the diagonal block)
-    const long long wait_ticks = ctl[2] > 0 ? (long long)ctl[2] : 200000000LL;
-    const bool inject = (ctl[1] & 1) != 0;
-    const __amdgpu_buffer_rsrc_t Lrs = __builtin_amdgcn_make_buffer_rsrc((void*)L, 0, (unsigned)((size_t)ld * ld * 4), 0x00020000);
-    const int Lvoff = (l31 + 4 * h * ld) * 4;
-    auto tile_soff = [&](int bi, int jc, int r) { return (unsigned)((bi * 32 + (size_t)(jc * 32 + (r & 3) + 8 * (r >> 2)) * ld) * 4); };
-    auto load_tile = [&](float (&o)[16], int b, int c) {
-        const int sbase = tri_index(b, c) * 4096;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            auto q = __builtin_amdgcn_raw_buffer_load_b128(Trs, Tvoff, sbase + gg * 1024, 0);
-            o[4 * gg + 0] = __uint_as_float(q[0]); o[4 * gg + 1] = __uint_as_float(q[1]);
-            o[4 * gg + 2] = __uint_as_float(q[2]); o[4 * gg + 3] = __uint_as_float(q[3]);
-        }
-    };
-    // What another workgroup reads inside this launch -- the re-tiled rows (Lt) and the factored diagonal block -- is stored
-    // WRITE-THROUGH (16-byte sc1 stores: the bytes leave this XCD's L2 at once), so a hand-over is "every storing wavefront
-    // drains its stores (vmcnt(0)), barrier, one lane moves the counter": no release fence, which would write back whatever
-    // else this XCD's L2 holds dirty at that moment (2-6 us per hand-over, twice per block column, on the serial path of the
-    // cluster).  The diagonal block travels as one 4 KB piece through the (j, j) slot of Zt -- K3b fills every Zt slot before it
-    // reads it, so the slot is free here.  The column-major factor L is read by the back-substitution only (after `alldone`,
-    // which keeps its release fence).
-    const __amdgpu_buffer_rsrc_t Zrs = __builtin_amdgcn_make_buffer_rsrc((void*)m.Zt, 0, (unsigned)ntl * 4096u, 0x00020000);
-    // one lane polls a device-scope flag, then the workgroup acquires; false: the wait expired or a partner aborted
-    int nwait = 0;
-    auto wait_flag = [&](int* f, int v) -> bool {
-        if (tid == 0) {
-            const long long t0 = wall_clock64();
-            int ok = 1;
-            for (;;) {
-                if (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= v) break;
-                if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 0) { ok = 0; break; }
-                if (wall_clock64() - t0 > wait_ticks) {
-                    ok = 0;
-                    atomicOr(ctl, 2);
-                    __hip_atomic_store(rowready, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            abort_s[nwait & 1] = !ok;
-        }
-        __syncthreads();
-        return abort_s[(nwait++) & 1] == 0;
-    };
-
-    // The tiles of one block row bi of column j: chain (needs row j's off-diagonal tiles), then -- once L_jj is there -- the
-    // solve, the stores and the incremental diagonal update.
-    // The products of a chain, operands two deep: the loads of product p + 1 are in flight while product p multiplies.  Straight-line
-    // trips (a tile index clamped to the last one instead of a branch around the loads: the last tile is simply requested again) with
-    // the order pinned -- with the loads inside `if (p + 1 < j)` the wait counts at the joins were conservative, and the sign flips of
-    // the NEXT tile's operand (vector instructions on freshly requested registers) were scheduled in front of the CURRENT product:
-    // every product waited for the loads issued just before it (coop trace: 0.65 us per product for 0.43 us of matrix instructions).
-    auto chain = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, j, r), 0));
-        if (j > 0) {
-            float a0[16], b0[16], a1[16], b1[16];
-            load_tile(a0, j, 0); load_tile(b0, bi, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll 1
-            for (int p = 0; p < j; p += 2) {
-                const int p1 = min(p + 1, j - 1);
-                load_tile(a1, j, p1); load_tile(b1, bi, p1);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a0[kk], b0[kk], acc, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int p2 = min(p + 2, j - 1);
-                load_tile(a0, j, p2); load_tile(b0, bi, p2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (p + 1 < j) {
-#pragma unroll
-                    for (int kk = 0; kk < 16; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(-a1[kk], b1[kk], acc, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    f32x16 dnext;          // wavefront 0: the accumulated diagonal block of the next pivot row, when this workgroup owns it
-    int dnext_row = -1;
-    auto finish = [&](f32x16& acc, int bi, int j) __attribute__((always_inline)) {
-        diag_solve32<true>(acc, Lc, h);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), Lrs, Lvoff, tile_soff(bi, j, r), 0);
-        float* T = Tt[wave];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) T[l31 * 36 + rowmap_t(r, h)] = -acc[r];   // Lt holds -L
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        float tq[16];      // -L(bi, j) in A-operand order
-        const int tbase = tri_index(bi, j) * 4096;
-#pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            float4 q;
-            q.x = T[l31 * 36 + 2 * (4 * gg + 0) + h];
-            q.y = T[l31 * 36 + 2 * (4 * gg + 1) + h];
-            q.z = T[l31 * 36 + 2 * (4 * gg + 2) + h];
-            q.w = T[l31 * 36 + 2 * (4 * gg + 3) + h];
-            u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
-            __builtin_amdgcn_raw_buffer_store_b128(qu, Trs, Tvoff, tbase + gg * 1024, 16);      // (aux 16 = sc1: write-through)
-            tq[4 * gg + 0] = q.x; tq[4 * gg + 1] = q.y; tq[4 * gg + 2] = q.z; tq[4 * gg + 3] = q.w;
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (bi < nb) {     // incremental diagonal of row bi: A(bi,bi) -= L(bi,j) L(bi,j)^T (rows without a pivot have none)
-            f32x16 dacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) dacc[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(bi, bi, r), 16));
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk) dacc = __builtin_amdgcn_mfma_f32_32x32x2f32(-tq[kk], tq[kk], dacc, 0, 0, 0);
-            if (bi == j + 1) {
-                // the next pivot block, complete with this update: it stays in the registers of the wavefront that factorises
-                // it in the next step (row j + 1 is always the first look-ahead row of its owner's wavefront 0)
-                dnext = dacc; dnext_row = bi;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dacc[r]), Lrs, Lvoff, tile_soff(bi, bi, r), 0);
-            }
-        }
-    };
-    auto publish = [&](int* f, int v) {      // one lane moves the counter; the write-through stores it announces were drained by their wavefronts before
-        if (tid == 0) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            // (an abort mark of a partner must survive: only move the counter forward from a non-negative value)
-            if (__hip_atomic_load(rowready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= 0)
-                __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-
-    // Look-ahead (round 3).  Two hand-overs per block column: "row j's off-diagonal tiles are final" (rowtiles, published by
-    // row j's owner BEFORE it factors the diagonal block) and "L_jj is there" (rowready).  Everybody accumulates the
-    // product chains of column j -- for up to two owned rows per wavefront, the accumulators wait in registers -- while
-    // the owner's wavefront 0 factorises; only the solves, the stores and the diagonal updates follow the second
-    // hand-over.  (Before: the whole chain of tile (j+1, j) sat between two diagonal factorisations, and the owner's
-    // other seven wavefronts idled through the factorisation.)  Same chains, same order: bit-identical.
-    for (int j = 0; j < nb; ++j) {
-        const int pw = min(32, K - 32 * j);
-        const bool owner = (j % G == g);
-        CSTAMP(0);
-        const int first = j + 1 + ((g - (j + 1)) % G + G) % G;     // first row > j owned by this workgroup
-        if (!owner && first >= nbr) continue;                       // nothing left for this workgroup in later columns either
-        const int bi0 = first + wave * G, bi1 = bi0 + NW * G;       // the two look-ahead rows of this wavefront
-        f32x16 acc0, acc1;
-        if (owner) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wavefront: its write-through tile stores of the previous steps have left
-            __syncthreads();           // this workgroup's stores of the previous steps (tiles of row j, its diagonal updates)
-            publish(rowtiles, j + 1);
-            CSTAMP(1);
-            if (wave != 0) {
-                if (bi0 < nbr) chain(acc0, bi0, j);
-                if (bi1 < nbr) chain(acc1, bi1, j);
-            } else {
-                // (device-scope loads: the block was modified by other wavefronts of this CU after it was last read here, and
-                // the vector L1 is not refreshed by stores)
-                // (aux 16 = sc1: the device-scope load of the agent-relaxed atomic this replaces -- served by L2, not the CU's L1)
-                f32x16 t;      // the accumulated diagonal block: lane = row, 16 of the 32 columns per lane half
-                if (dnext_row == j) t = dnext;      // (kept by this wavefront at the end of the previous step)
-                else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) t[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(Lrs, Lvoff, tile_soff(j, j, r), 16));
-                }
-                if (pw == 32) {
-                    // micro-blocked factorisation in accumulator layout (tile_solve.h: same operations in the same order as
-                    // factor32_inreg, the trailing updates of a micro-block as four matrix instructions): about half the cycles
-                    // of the column-by-column sweep, and it sits on the serial path of every block column
-                    factor32_mb<0>(t, l31, h, lane, Lc);
-                    factor32_mb<1>(t, l31, h, lane, Lc);
-                    factor32_mb<2>(t, l31, h, lane, Lc);
-                    factor32_mb<3>(t, l31, h, lane, Lc);
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 32) {
-#pragma unroll
-                        for (int c = 0; c < 32; ++c)
-                            if (c <= lane) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Lc[c * 32 + lane]), Lrs, lane * 4, (unsigned)((j * 32 + (size_t)(j * 32 + c) * ld) * 4), 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) D[l31 * 33 + rowmap_t(r, h)] = t[r];
-                    __builtin_amdgcn_s_waitcnt(0xc07f);
-                    __builtin_amdgcn_wave_barrier();
-                    volatile float __attribute__((address_space(3)))* Dv = (volatile float __attribute__((address_space(3)))*)D;   // (explicit LDS pointer: volatile accesses through a generic pointer become flat ones whose 64-bit addresses are hoisted and spilled)
-                    for (int c = 0; c < pw; ++c) {
-                        float d = sqrtf(Dv[c * 33 + c]);
-                        float lij = 0.f;
-                        const bool below = (lane > c && lane < 32);
-                        if (below) lij = Dv[lane * 33 + c] / d;
-                        if (lane == c) Dv[c * 33 + c] = d;
-                        if (below) Dv[lane * 33 + c] = lij;
-                        if (below) {
-                            const float nl = -lij;
-                            const int kend = min(lane, pw - 1);
-                            for (int k = c + 1; k <= kend; ++k) Dv[lane * 33 + k] = fmaf(nl, Dv[k * 33 + c], Dv[lane * 33 + k]);
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 32) {
-                        for (int c = 0; c < 32; ++c) {
-                            float v = Dv[lane * 33 + c];
-                            Lc[c * 32 + lane] = (lane < pw && c < pw) ? v : (lane == c ? 1.f : 0.f);
-                            if (c < pw && c <= lane) L[(size_t)(j * 32 + lane) + (size_t)(j * 32 + c) * ld] = v;
-                        }
-                    }
-                }
-                // The padded block as the partners will use it (Lc), 4 KB write-through into the (j, j) slot of Zt.  It was written
-                // by this wavefront alone: it hands the block over itself, at once -- the partners' solves of column j need not
-                // wait for the other seven wavefronts' product chains (the barrier below).
-                __builtin_amdgcn_s_waitcnt(0xc07f);
-                __builtin_amdgcn_wave_barrier();
-                {
-                    const int zbase = tri_index(j, j) * 4096;
-#pragma unroll
-                    for (int gg = 0; gg < 4; ++gg) {
-                        const float4 q = reinterpret_cast<const float4*>(Lc)[gg * 64 + lane];
-                        u32x4 qu = {__float_as_uint(q.x), __float_as_uint(q.y), __float_as_uint(q.z), __float_as_uint(q.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(qu, Zrs, Tvoff, zbase + gg * 1024, 16);
-                    }
-                }
-                if (!(inject && j == 1)) publish(rowready, j + 1);
-            }
-            CSTAMP(3);
-            __syncthreads();           // L_jj in Lc for this workgroup's own solves; the other wavefronts' chains are accumulated
-            if (wave == 0) {
-                // inv(L_jj) -> diagonal slot of Lt, in the k order of an accumulator tile (K3b / the blocked solves use it).  After
-                // the hand-over: nobody in this kernel reads it.
-                f32x16 x;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) x[r] = (rowmap_t(r, h) == l31) ? 1.f : 0.f;
-                diag_solve32<true>(x, Lc, h);
-                float* Dt = m.Lt + (size_t)tri_index(j, j) * 1024 + (((l31 >> 3) * 64 + ((l31 >> 2) & 1) * 32) * 4 + (l31 & 3));
-#pragma unroll
-                for (int r = 0; r < 16; ++r) Dt[rowmap_t(r, h) * 4] = x[r];
-                if (bi0 < nbr) chain(acc0, bi0, j);
-                if (bi1 < nbr) chain(acc1, bi1, j);
-                CSTAMP(2);
-            }
-            if (first >= nbr) continue;
-        } else {
-            if (!wait_flag(rowtiles, j + 1)) return;      // expired / aborted: error word set, the cluster is abandoned
-            CSTAMP(1);
-            if (bi0 < nbr) chain(acc0, bi0, j);
-            if (bi1 < nbr) chain(acc1, bi1, j);
-            CSTAMP(2);
-            if (!wait_flag(rowready, j + 1)) return;
-            // non-owners copy the published (padded) diagonal factor
-            if (tid < 256) {
-                auto q = __builtin_amdgcn_raw_buffer_load_b128(Zrs, tid * 16, tri_index(j, j) * 4096, 16);
-                reinterpret_cast<float4*>(Lc)[tid] = make_float4(__uint_as_float(q[0]), __uint_as_float(q[1]), __uint_as_float(q[2]), __uint_as_float(q[3]));
-            }
-            __syncthreads();
-            CSTAMP(3);
-        }
-        if (bi0 < nbr) finish(acc0, bi0, j);
-        CSTAMP(4);
-        if (bi1 < nbr) finish(acc1, bi1, j);
-        for (int bi = bi1 + NW * G; bi < nbr; bi += NW * G) {     // (more than two rows per wavefront: the rest without look-ahead)
-            f32x16 acc;
-            chain(acc, bi, j);
-            finish(acc, bi, j);
-        }
-        CSTAMP(6);
-    }
-    // ---- all rows done: workgroup 0 runs the back-substitution over the complete factor
-    __syncthreads();
-    if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(alldone, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (g != 0) return;
-    if (!wait_flag(alldone, G)) return;
-    chol_epilogue<512>(m, &Tt[0][0], NW * 32 * 36, av, tid, lane, wave);
-}
-
-// ---------------------------------------------------------------------------
-// K3 for a FEW large clusters (round 6): the cooperative factorisation as a data flow, no workgroup barriers in the sweep.
-// The trace of the kernel above (profiles/r06_k3_coop_trace.txt) shows every wavefront busy, not waiting: the tiles of a block row
-// are one chain after the other in ONE wavefront per column (0.6 us per product + 3.7 us solve / store / diagonal update), so a
-// cluster of 38 block rows cannot finish before ~0.55 ms whatever G is.  Here block row r belongs to TWO wavefronts, one for the
-// even and one for the odd columns: while tile (r, j) waits for its last operands and is solved, the other wavefront already
-// accumulates tile (r, j + 1) as far as its operands exist.  Progress is per ROW: prog[r] = number of leading tiles of row r that
-// are final, diag[r] = L_rr is in its Zt slot.  A product p of tile (r, j) needs prog[j] > p and prog[r] > p; the solve needs
-// diag[j]; the wavefront that finishes tile (r, r - 1) holds the completed diagonal block and factorises it at once.  Tiles are
-// stored write-through and announced after vmcnt(0) (as above); a tile is never read before it is final, the diagonal blocks
-// travel through device-scope loads: no cache maintenance.  Every element keeps its chain: bit-identical to the kernels above.
-// Waits are bounded (ctl[2] ticks): error word bit 1 + abort mark, as above.  The G workgroups of a cluster are resident together
-// (one per CU, launch <= capacity); wavefront v = 8 g + w takes the tasks (row, parity) t = v, v + 8 G, ... of 2 (rows - 1).
+// K3 for the LARGEST clusters: G cooperating workgroups per cluster (one per CU), the factorisation as a DATA FLOW.
+// A single workgroup needs ~15 ms for a K = 2300 factorisation (74 dependent block columns on one CU) while the rest of the chip
+// idles.  The sweep is still left-looking and every element keeps its ascending-(p, k) fmaf chain (bit-identical to the
+// single-workgroup kernel):
+//     T = A(r, j) - sum_{p < j} L(r, p) L(j, p)^T ;  L(r, j) = T L_jj^-T ;  A(r, r) -= L(r, j) L(r, j)^T   (incremental diagonal:
+//     when row r becomes the pivot row its diagonal block only needs the factorisation)
+// Rounds 3-5 ran this with one owner workgroup per block row, two device-scope hand-overs per block column and workgroup
+// barriers around them (git: d9fa161 and before); a wall-clock trace of that kernel (profiles/r06_k3_coop_trace.txt) showed every
+// wavefront BUSY, not waiting: the tiles of a block row were one chain after the other in ONE wavefront per column (0.6 us per
+// product + 3.7 us solve / store / diagonal update), so a cluster of 38 block rows could not finish before ~0.55 ms whatever G.
+// Here block row r belongs to TWO wavefronts, one for the even and one for the odd columns: while tile (r, j) waits for its last
+// operands and is solved, the other wavefront already accumulates tile (r, j + 1) as far as its operands exist.  Progress is per
+// ROW: prog[r] = number of leading tiles of row r that are final, diag[r] = L_rr sits in its Zt slot.  Product p of tile (r, j)
+// needs prog[j] > p and prog[r] > p; the solve needs diag[j]; the wavefront that finishes tile (r, r - 1) holds the completed
+// diagonal block and factorises it at once.  No workgroup barrier in the sweep.  Tiles are stored write-through (sc1) and
+// announced after vmcnt(0); a tile is never read before it is final and the diagonal blocks travel through device-scope loads:
+// no cache maintenance.  The launch holds at most one workgroup per CU (<= the device's budget), so every workgroup of a
+// cluster is resident and the waits end; they are bounded all the same (ctl[2] ticks of the 100 MHz clock, default 2 s): on
+// expiry error word bit 1 + the cluster's abort mark, the host reports GPIS_ERR_STATE (the batch is dropped).  ctl[1] bit 0 is
+// test-only fault injection: the factor of block row 1 is never announced.
+// Wavefront v = 8 g + w takes the tasks (row, parity) t = v, v + 8 G, ... of 2 (rows - 1), column by column.
 // flags = sync + sync[3 job + 2]: [0 .. rows) prog, [rows .. 2 rows) diag; sync[3 job] < 0 = abort, sync[3 job + 1] = workgroups done.
+// The blocked back-substitution for alpha runs on workgroup 0 of the cluster after all rows are done.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(512, 2) void ongpis_chol_flow_kernel(const ClusterModel* __restrict__ models,
                                                                 const int* __restrict__ d_jobs, const int* __restrict__ cwork,
@@ -1564,12 +1247,6 @@ void ongpis_launch_chol_async(const ClusterModel* d_models, const int* d_jobs, i
     if (njobs > 0) hipLaunchKernelGGL(ongpis_chol_async_kernel, dim3(njobs), dim3(512), 0, s, d_models, d_jobs, d_ctl);
 }
 #endif
-void ongpis_launch_chol_coop(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {
-    if (nwg > 0) hipLaunchKernelGGL(ongpis_chol_coop_kernel, dim3(nwg), dim3(512), 0, s, d_models, d_jobs, d_cwork, d_sync, d_ctl);
-#ifdef GPIS_INSTRUMENT
-    if (nwg > 0 && getenv("GPIS_COOP_TRACE")) coop_trace_dump(s, nwg);
-#endif
-}
 // workgroups of the cooperative kernel that can be resident at once on the current device (its waits need every workgroup
 // of a cluster running): CUs x occupancy, less a sixteenth as a margin for the kernels of the other size groups
 void ongpis_launch_chol_flow(const ClusterModel* d_models, const int* d_jobs, const int* d_cwork, int nwg, int* d_sync, int* d_ctl, hipStream_t s) {

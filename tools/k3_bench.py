@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Micro-benchmark of the K > 256 training chain (gather, build, chol / chol_coop, inverse) through the kernel-level C-ABI:
+"""Micro-benchmark of the K > 256 training chain (gather, build, chol / chol_flow, inverse) through the kernel-level C-ABI:
 M clusters of N points (K ~ 3.4 N).  Prints the ms of the timed second batch and the tile products per microsecond."""
 import os
 import sys
