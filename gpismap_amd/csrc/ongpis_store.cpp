@@ -662,7 +662,7 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         coop_dev_ = coop_dev; coop_held_ = total;
         size_t mx = 0;
         for (int x = 0; x < 8; ++x) mx = std::max(mx, sub[x].size() / 3);
-        for (size_t k = 0; k < mx && total > 0; ++k)
+        for (size_t k = 0; k < mx && ncoop > 0; ++k)
             for (int x = 0; x < 8; ++x) {
                 if (3 * k < sub[x].size()) { cwork.push_back(sub[x][3 * k]); cwork.push_back(sub[x][3 * k + 1]); cwork.push_back(sub[x][3 * k + 2]); }
                 else { cwork.push_back(-1); cwork.push_back(0); cwork.push_back(1); }
