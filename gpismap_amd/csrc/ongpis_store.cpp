@@ -641,12 +641,12 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
             total += G;
         }
         // ... then, in a batch that leaves the device room (the latency regimes above), what is left of the budget goes to the
-        // largest clusters until each block row has its two wavefronts (8 G >= 2 rows: tools/k3_bench.py, one K = 1190 cluster
+        // largest clusters until each block row has up to four wavefronts (8 G >= 4 rows: tools/k3_bench.py, one K = 1190 cluster
         // 0.84 ms with G = 6, 0.78 with 10; K = 680 0.44 / 0.36)
         if (kCoopGDiv < 900) {
             for (size_t j = 0; j < Gs.size() && total < kCoopMaxWG; ++j) {
                 const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
-                const int want = std::min(16, std::max(Gs[j], (nbj + 3) / 4));
+                const int want = std::min(32, std::max(Gs[j], (nbj + 1) / 2));      // (up to four wavefronts per block row; 32 CUs = one XCD)
                 const int add = std::min(want - Gs[j], kCoopMaxWG - total);
                 Gs[j] += add; total += add;
             }

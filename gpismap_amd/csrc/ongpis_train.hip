@@ -684,8 +684,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : (NW == 4 ? 2 : K3_T
 // barriers around them (git: d9fa161 and before); a wall-clock trace of that kernel (profiles/r06_k3_coop_trace.txt) showed every
 // wavefront BUSY, not waiting: the tiles of a block row were one chain after the other in ONE wavefront per column (0.6 us per
 // product + 3.7 us solve / store / diagonal update), so a cluster of 38 block rows could not finish before ~0.55 ms whatever G.
-// Here block row r belongs to TWO wavefronts, one for the even and one for the odd columns: while tile (r, j) waits for its last
-// operands and is solved, the other wavefront already accumulates tile (r, j + 1) as far as its operands exist.  Progress is per
+// Here block row r belongs to M = 2 .. 4 wavefronts that take its tiles in turn by column: while tile (r, j) waits for its last
+// operands and is solved, the next wavefront already accumulates tile (r, j + 1) as far as its operands exist.  Progress is per
 // ROW: prog[r] = number of leading tiles of row r that are final, diag[r] = L_rr sits in its Zt slot.  Product p of tile (r, j)
 // needs prog[j] > p and prog[r] > p; the solve needs diag[j]; the wavefront that finishes tile (r, r - 1) holds the completed
 // diagonal block and factorises it at once.  No workgroup barrier in the sweep.  Tiles are stored write-through (sc1) and
@@ -694,7 +694,8 @@ __global__ __launch_bounds__(64 * NW, NW == 1 ? K3_T1_MINW : (NW == 4 ? 2 : K3_T
 // cluster is resident and the waits end; they are bounded all the same (ctl[2] ticks of the 100 MHz clock, default 2 s): on
 // expiry error word bit 1 + the cluster's abort mark, the host reports GPIS_ERR_STATE (the batch is dropped).  ctl[1] bit 0 is
 // test-only fault injection: the factor of block row 1 is never announced.
-// Wavefront v = 8 g + w takes the tasks (row, parity) t = v, v + 8 G, ... of 2 (rows - 1), column by column.
+// Wavefront v = 8 g + w takes the tasks (row, column class) t = v, v + 8 G, ... of M (rows - 1), column by column; M = 2 .. 4
+// wavefronts per row, as many as 8 G provides.
 // flags = sync + sync[3 job + 2]: [0 .. rows) prog, [rows .. 2 rows) diag; sync[3 job] < 0 = abort, sync[3 job + 1] = workgroups done.
 // The blocked back-substitution for alpha runs on workgroup 0 of the cluster after all rows are done.
 // ---------------------------------------------------------------------------
@@ -832,7 +833,9 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_flow_kernel(const ClusterM
     };
 
     const int v = g * NW + wave, V = G * NW;
-    const int ntask = 2 * (nbr - 1);
+    // wavefronts per block row: two, or as many as the cluster's workgroups provide (the tiles of a row go round them by column)
+    const int M = max(2, min(4, V / max(1, nbr - 1)));
+    const int ntask = M * (nbr - 1);
     int have_diag = -1;                   // the pivot row whose factor sits in this wavefront's Lc
     bool ok = true;
     if (v == 0) {                         // row 0 has no tiles: its diagonal block is the kernel matrix's, factorised before tile (1, 0)
@@ -842,10 +845,14 @@ __global__ __launch_bounds__(512, 2) void ongpis_chol_flow_kernel(const ClusterM
         pivot(t, 0);
         have_diag = 0;
     }
-    for (int j = 0; j < nb && ok; ++j) {
+    const int r_first = v / M + 1, q_first = v % M, r_step = V / M, q_step = V % M;     // task t = v + i V is (row t / M + 1, class t % M): stepped, not divided
+    for (int j = 0, jm = 0; j < nb && ok; ++j, jm = (jm + 1 == M) ? 0 : jm + 1) {
+        int r = r_first - r_step, q = q_first - q_step;
         for (int t = v; t < ntask && ok; t += V) {
-            const int r = (t >> 1) + 1;
-            if ((t & 1) != (j & 1) || r <= j) continue;
+            r += r_step; q += q_step;
+            if (q >= M) { q -= M; ++r; }
+            if (q < 0) { q += M; --r; }
+            if (q != jm || r <= j) continue;
             // ---- tile (r, j): T = A(r, j) - sum_{p < j} L(r, p) L(j, p)^T, products as far as both rows have got
             f32x16 acc;
 #pragma unroll
