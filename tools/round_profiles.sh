@@ -7,6 +7,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 export ROUND=${ROUND:-r06}
 R=$ROUND
+# FIRST, before any profiler run: the pipelined update needs its kernels to overlap, and for a while after a rocprofv3 counter
+# collection (which serialises kernels) the device still runs them one at a time -- frames of 40-60 ms that are not the library's
+python3 tools/update_pipeline.py 8 2>&1 | tail -5 > gpurun_out/${R}_update_pipeline.txt
 # The kernel-stats collection runs the SAME bench command with one update fusion and the size-class launches of small test() passes
 # on one stream: with several fusions and the forked side streams the process holds more HIP streams than hardware queues, and the
 # profiler's per-dispatch intervals of kernels on oversubscribed queues include the time they sat behind each other (the r04 file:
@@ -41,7 +44,6 @@ bash tools/measure_traffic.sh > /dev/null 2>&1
 bash tools/update_pmc.sh traffic > /dev/null 2>&1; cp gpurun_out/update_pmc.txt gpurun_out/${R}_update_pmc.txt
 bash tools/update_pmc.sh sq > /dev/null 2>&1; cat gpurun_out/update_pmc.txt >> gpurun_out/${R}_update_pmc.txt
 bash tools/update_timeline.sh 5 > /dev/null 2>&1; { cat gpurun_out/update_profile.txt; grep -E "ongpis|obsgp|fused" gpurun_out/update_timeline.txt; } > gpurun_out/${R}_update_timeline.txt
-python3 tools/update_pipeline.py 8 2>&1 | tail -5 > gpurun_out/${R}_update_pipeline.txt
 bash tools/k4_curve.sh > /dev/null 2>&1
 # K4 cycle stamps (instrumented build, tools/ab/lib_instr.so = `bash tools/ab_full.sh instr -DGPIS_INSTRUMENT` of the same source): bench pass, then two small sizes
 if [ -f tools/ab/lib_instr.so ]; then
