@@ -16,6 +16,7 @@
 #include <algorithm>
 #include "ongpis.h"
 #include "tile_solve.h"
+#include "exp_tab.h"
 
 namespace gpis {
 
@@ -146,6 +147,10 @@ __global__ __launch_bounds__(256) void ongpis_buildK_kernel(const ClusterModel* 
     const float a2 = a * a;
     const float4* x4 = reinterpret_cast<const float4*>(m.x4);
     const int nbr = ld / 32, ntl = nbr * (nbr + 1) / 2;
+    // (the exponential of K4 and K2 -- exp_tab.h: 2^(j/64) table in LDS + degree-6 polynomial -- and the ranged square root)
+    __shared__ f64x2 s_exp[64];
+    if (tid < 64) s_exp[tid] = *reinterpret_cast<const f64x2*>(kExp64Tab[tid]);
+    __syncthreads();
     for (int t = blockIdx.y * 4 + wave; t < ntl; t += 4 * gridDim.y) {
         int b = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
         while (tri_index(b + 1, 0) <= t) ++b;
@@ -180,8 +185,8 @@ __global__ __launch_bounds__(256) void ongpis_buildK_kernel(const ClusterModel* 
                     const float4 xk = row_first ? xr : xc, xj = row_first ? xc : xr;
                     const int ck = row_first ? cr : cc, cj = row_first ? cc : cr;   // 0: value row, 1..3: gradient component + 1
                     const float d0 = xk.x - xj.x, d1 = xk.y - xj.y, d2 = xk.z - xj.z;
-                    const float r = (dim == 3) ? sqrtf((d0 * d0 + d1 * d1) + d2 * d2) : sqrtf(d0 * d0 + d1 * d1);
-                    const double e = exp((double)(-a * r));
+                    const float r = sqrt_ranged((dim == 3) ? (d0 * d0 + d1 * d1) + d2 * d2 : d0 * d0 + d1 * d1);      // (= sqrtf: squared distances are 0 or far above 2^-96)
+                    const double e = exp_neg_tab(-a * r, s_exp);
                     auto comp = [&](int q) { return q == 1 ? d0 : (q == 2 ? d1 : d2); };
                     if (ck == 0 && cj == 0) v = d_kf(r, a, e);
                     else if (cj == 0) v = -d_kf1(comp(ck), a, e);
