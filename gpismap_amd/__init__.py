@@ -114,6 +114,8 @@ def lib():
     L.gpis_ongpis_set_exp_table.argtypes = [vp, C.c_int]
     L.gpis_ongpis_kernel_matrix.argtypes = [vp, fp, ip, fp, fp, C.c_int, fp]
     L.gpis_ongpis_set_debug.argtypes = [vp, C.c_int, C.c_int]
+    if hasattr(L, "gpis_ongpis_set_cu_reserve"):
+        L.gpis_ongpis_set_cu_reserve.argtypes = [vp, C.c_int]
     if hasattr(L, "gpis_selftest_ranged_arith"):       # (A/B runs load older builds of the library through GPISMAP_AMD_LIB)
         L.gpis_selftest_ranged_arith.argtypes = [C.c_ulonglong, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
         L.gpis_selftest_ranged_arith.restype = C.c_int
@@ -540,6 +542,10 @@ class OnGPIS:
         """Bound of the in-kernel waits (0 = default 2 s) and the test-only fault injection: inject bit 0 = the cooperative
         factorisation withholds a hand-over, bit 4 (16) = the first workgroup of every prediction launch withholds one ring signal."""
         _check(self.L.gpis_ongpis_set_debug(self.h, int(inject), int(wait_limit_ms)), "gpis_ongpis_set_debug")
+
+    def set_cu_reserve(self, n):
+        """CUs the training streams of this handle leave free (CU-masked streams, as the maps' pipelined update uses them)."""
+        _check(self.L.gpis_ongpis_set_cu_reserve(self.h, int(n)), "gpis_ongpis_set_cu_reserve")
 
     def set_lazy_inverse(self, on=True):
         _check(self.L.gpis_ongpis_set_lazy_inverse(self.h, 1 if on else 0), "gpis_ongpis_set_lazy_inverse")

@@ -364,6 +364,19 @@ int gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms) {
     h->st.wait_limit_ticks = wait_limit_ms * 100000;     // 100 MHz device clock
     return GPIS_OK;
 }
+int gpis_ongpis_set_cu_reserve(void* s, int n) {
+    if (!s || n < 0) return GPIS_ERR_ARG;
+    OnHandle* h = (OnHandle*)s;
+    DeviceScope dev_scope_(h->device);
+    const int rc = h->st.set_cu_reserve(n);      // (joins a batch in flight, re-creates the side streams at the next training)
+    if (rc != GPIS_OK) return rc;
+    // the handle's own stream carries the largest clusters (the cooperative launch): masked like the others
+    hipStream_t ns = nullptr;
+    if (int src = ongpis_make_train_stream(&ns, n)) return src;
+    if (h->s) { (void)hipStreamSynchronize(h->s); (void)hipStreamDestroy(h->s); }
+    h->s = ns;
+    return GPIS_OK;
+}
 int gpis_ongpis_last_ms(void* s, float* t, float* e) {
     if (!s) return GPIS_ERR_ARG;
     OnHandle* h = (OnHandle*)s;

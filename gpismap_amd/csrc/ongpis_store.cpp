@@ -644,10 +644,15 @@ int OnGPISStore::train_enqueue(const std::vector<TrainJob>& jobs, const std::vec
         // largest clusters until each block row has up to four wavefronts (8 G >= 4 rows: tools/k3_bench.py, one K = 1190 cluster
         // 0.84 ms with G = 6, 0.78 with 10; K = 680 0.44 / 0.36)
         if (kCoopGDiv < 900) {
+            // (a cluster's workgroups sit on ONE XCD and must all be resident: 32 CUs, or what the training streams' CU mask leaves of
+            // them -- bit i of the mask is CU i / 8 of XCD i % 8, so a reserve of 64 leaves 24 per XCD)
+            int ncu = 0;
+            if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, coop_dev) != hipSuccess) ncu = 256;
+            const int per_xcd = std::max(2, (ncu - std::max(0, cu_reserve_)) / 8);
             for (size_t j = 0; j < Gs.size() && total < kCoopMaxWG; ++j) {
                 const int nbj = (tab[4 * j + 2] + dim_ * tab[4 * j + 3] + 31) / 32;
-                const int want = std::min(32, std::max(Gs[j], (nbj + 1) / 2));      // (up to four wavefronts per block row; 32 CUs = one XCD)
-                const int add = std::min(want - Gs[j], kCoopMaxWG - total);
+                const int want = std::min(per_xcd, std::max(Gs[j], (nbj + 1) / 2));      // (up to four wavefronts per block row)
+                const int add = std::max(0, std::min(want - Gs[j], kCoopMaxWG - total));
                 Gs[j] += add; total += add;
             }
         }

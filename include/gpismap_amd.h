@@ -238,6 +238,10 @@ int   gpis_ongpis_set_lazy_inverse(void* s, int on);
  * bounded wait): its tile's results are NaN, the error word of the launch is raised and gpis_ongpis_eval / test() return
  * GPIS_ERR_STATE -- so that the error paths can be exercised. */
 int   gpis_ongpis_set_debug(void* s, int inject, int wait_limit_ms);
+/* CUs the training streams of this handle leave free (what the maps do for their pipelined update: gpis3_set_pipeline /
+ * GPIS_PIPELINE_RESERVE_CUS).  The streams are created with a CU mask over the first (CUs - n) bits -- bit i is CU i / 8 of XCD
+ * i % 8 -- and the cooperative factorisation sizes its workgroup groups for what is left on one XCD.  0 = ordinary streams. */
+int   gpis_ongpis_set_cu_reserve(void* s, int n);
 /* Device self-test (round 6): the factorisation kernels take their square roots and divisions through range-restricted sequences
  * (csrc/tile_solve.h: the compiler's correctly rounded expansions without the operand scaling and classification the chains'
  * operands never need).  Runs blocks * 256 * per_thread random operand pairs through them and through the compiler's sqrtf and `/`

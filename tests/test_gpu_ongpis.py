@@ -273,6 +273,34 @@ def test_cooperative_wait_expiry_is_reported():
     assert np.array_equal(np.concatenate([out[:, :4], out[:, 4:8]], axis=1).view(np.uint32), ref.view(np.uint32))
 
 
+def test_cooperative_groups_fit_the_cus_a_masked_stream_leaves_on_one_xcd():
+    """A cooperative cluster's workgroups sit on one XCD and must all be resident.  The pipelined update trains on CU-masked
+    streams (64 CUs reserved: 24 of an XCD's 32 left); a cluster that the batch leaves room for gets up to four wavefronts per
+    block row -- 32 workgroups on ordinary streams, and no more than the mask leaves of an XCD on masked ones (the schedule's cap;
+    on the boxes seen the uncapped 32 did become resident all the same).  The factor, alpha and the predictions must not depend on
+    how many workgroups / wavefronts per row shared the work: three different splits, the same bits."""
+    import gpismap_amd
+    rng = np.random.default_rng(77)
+    n = 600
+    pos, grad, val, sx, sg = make_cluster(rng, 3, n, 0.04, frac_nograd=0.0)      # K = 2400: 75 block rows -> wants 32 workgroups
+    P = soa9(3, pos, grad, val, sx, sg)
+    off = np.array([0, n], dtype=np.int32); ids = np.arange(n, dtype=np.int32)
+    xq = (pos[:64] + rng.normal(0, 0.01, (64, 3))).astype(np.float32)
+    outs = []
+    for reserve in (0, 64, 128):
+        st = gpismap_amd.OnGPIS(3, 0.04)
+        st.set_debug(inject=0, wait_limit_ms=500)
+        st.set_cu_reserve(reserve)
+        models = st.train(P, off, ids)
+        m = st.model(models[0])
+        out = st.eval(xq, np.arange(64, dtype=np.int32), np.full(64, models[0], dtype=np.int32))
+        outs.append((np.tril(m["L"][:m["K"], :m["K"]]).copy(), m["alpha"].copy(), out.copy()))      # (above the diagonal: scratch)
+    for o in outs[1:]:
+        assert np.array_equal(o[0].view(np.uint32), outs[0][0].view(np.uint32))
+        assert np.array_equal(o[1].view(np.uint32), outs[0][1].view(np.uint32))
+        assert np.array_equal(o[2].view(np.uint32), outs[0][2].view(np.uint32))
+
+
 def test_query_on_a_training_point_reproduces_the_references_nan():
     """kf2 divides by r, so a query that coincides with a gradient-bearing training point makes the
     reference's cross-covariance NaN (covFnc.cpp:31-33, no guard) and with it the whole prediction of that query.  The
