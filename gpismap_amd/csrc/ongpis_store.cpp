@@ -501,7 +501,33 @@ int OnGPISStore::ensure_inverses(hipStream_t s) {
         if (!ev0_) { GPIS_HIP(hipEventCreate(&ev0_)); GPIS_HIP(hipEventCreate(&ev1_)); }
         GPIS_HIP(hipEventRecord(ev0_, s));
     }
-    ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off, nlong, nmid, nshort, d_err_, s);
+    // The three column classes are independent launches (a block column of X depends on no other): side by side on two forked
+    // streams instead of one after the other -- at the first test() after an update of a few dozen clusters each of them is a
+    // handful of latency-bound workgroups (data/3D: 0.32 + 0.32 ms per frame in a row).
+    if ((nlong > 0) + (nmid > 0) + (nshort > 0) > 1) {
+        if (!s2_) {
+            if (int src = ongpis_make_train_stream(&s2_, cu_reserve_)) return src;
+            if (int src = ongpis_make_train_stream(&s3_, cu_reserve_)) return src;
+        }
+        if (!evf_) {
+            GPIS_HIP(hipEventCreateWithFlags(&evf_, hipEventDisableTiming));
+            GPIS_HIP(hipEventCreateWithFlags(&evj_, hipEventDisableTiming));
+            GPIS_HIP(hipEventCreateWithFlags(&evj3_, hipEventDisableTiming));
+        }
+        GPIS_HIP(hipEventRecord(evf_, s));
+        ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off, nlong, 0, 0, d_err_, s);
+        if (nmid > 0) {
+            GPIS_HIP(hipStreamWaitEvent(s2_, evf_, 0));
+            ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off + 2 * nlong, 0, nmid, 0, d_err_, s2_);
+            GPIS_HIP(hipEventRecord(evj_, s2_)); GPIS_HIP(hipStreamWaitEvent(s, evj_, 0));
+        }
+        if (nshort > 0) {
+            hipStream_t ss = (nlong > 0 || nmid == 0) ? s3_ : s;      // (two classes only: one of them stays on the caller's stream)
+            if (ss != s) GPIS_HIP(hipStreamWaitEvent(ss, evf_, 0));
+            ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off + 2 * (nlong + nmid), 0, 0, nshort, d_err_, ss);
+            if (ss != s) { GPIS_HIP(hipEventRecord(evj3_, ss)); GPIS_HIP(hipStreamWaitEvent(s, evj3_, 0)); }
+        }
+    } else ongpis_launch_inverse(d_models_, d_jobs_, d_work_ + off, nlong, nmid, nshort, d_err_, s);
     GPIS_HIP(hipGetLastError());
     if (profile) GPIS_HIP(hipEventRecord(ev1_, s));
     for (int i = 0; i < 4; ++i) h_err_[i] = 0;
