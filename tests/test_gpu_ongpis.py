@@ -301,6 +301,32 @@ def test_cooperative_groups_fit_the_cus_a_masked_stream_leaves_on_one_xcd():
         assert np.array_equal(o[2].view(np.uint32), outs[0][2].view(np.uint32))
 
 
+def test_cooperative_factorisation_is_the_same_every_time():
+    """The cooperative kernel is a data flow: which wavefront gets how far before it has to wait depends on timing.  The result
+    must not -- every element is one fmaf chain in a fixed order whoever computes it.  A mixed batch (clusters of 5 to 20 block rows
+    one-workgroup, larger ones cooperative with different numbers of workgroups) trained six times: the same bits every time."""
+    import gpismap_amd
+    rng = np.random.default_rng(5)
+    sizes = [120 + 26 * i for i in range(20)] + [650]
+    cl = [make_cluster(rng, 3, n, 0.04) for n in sizes]
+    P = soa9(3, *[np.concatenate([c[i] for c in cl]) for i in range(5)])
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    ids = np.arange(off[-1], dtype=np.int32)
+    ref = None
+    for rep in range(6):
+        st = gpismap_amd.OnGPIS(3, 0.04)
+        models = st.train(P, off, ids)
+        got = []
+        for slot in models:
+            m = st.model(slot)
+            got.append((np.tril(m["L"][:m["K"], :m["K"]]).view(np.uint32).copy(), m["alpha"].view(np.uint32).copy()))
+        if ref is None:
+            ref = got
+        else:
+            for a, b in zip(ref, got):
+                assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_query_on_a_training_point_reproduces_the_references_nan():
     """kf2 divides by r, so a query that coincides with a gradient-bearing training point makes the
     reference's cross-covariance NaN (covFnc.cpp:31-33, no guard) and with it the whole prediction of that query.  The
