@@ -327,6 +327,32 @@ def test_cooperative_factorisation_is_the_same_every_time():
                 assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
 
 
+def test_cluster_beyond_the_lds_buffer_of_the_back_substitution():
+    """K > 9216: the target vector no longer fits the back substitution's LDS buffer, so alpha takes the barrier path through the
+    model's global scratch -- the one branch of the training kernels no other test reaches (the oracle needs minutes for such a
+    cluster).  Checked against float64 LAPACK on the GPU-built kernel matrix: K alpha = y to fp32 accuracy, alpha within 2e-3 of the
+    float64 solution (1e-4 / 3e-4 measured; 2e-5 / 1e-4 at K = 1200, where the oracle comparison is bit-exact)."""
+    import gpismap_amd
+    rng = np.random.default_rng(3)
+    n = 2330
+    pos, grad, val, sx, sg = make_cluster(rng, 3, n, 0.11, frac_nograd=0.0)      # the patch of a 300-point cluster scaled to the same density
+    P = soa9(3, pos, grad, val, sx, sg)
+    off = np.array([0, n], dtype=np.int32); ids = np.arange(n, dtype=np.int32)
+    st = gpismap_amd.OnGPIS(3, 0.04)
+    models = st.train(P, off, ids)
+    m = st.model(models[0])
+    assert m["K"] == 4 * n and m["K"] > 9216
+    alpha = m["alpha"].astype(np.float64)
+    assert np.isfinite(alpha).all()
+    Km = st.kernel_matrix(pos, m["gidx"], sx, sg).astype(np.float64)
+    Kf = np.tril(Km) + np.tril(Km, -1).T
+    del Km
+    y = np.concatenate([val.astype(np.float64)] + [grad[:, c].astype(np.float64) for c in range(3)])
+    assert np.abs(Kf @ alpha - y).max() < 1e-3 * np.abs(y).max()
+    a64 = np.linalg.solve(Kf, y)
+    assert np.abs(a64 - alpha).max() < 2e-3 * np.abs(a64).max()
+
+
 def test_query_on_a_training_point_reproduces_the_references_nan():
     """kf2 divides by r, so a query that coincides with a gradient-bearing training point makes the
     reference's cross-covariance NaN (covFnc.cpp:31-33, no guard) and with it the whole prediction of that query.  The
